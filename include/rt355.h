@@ -1,0 +1,194 @@
+/*
+ * rt355.h -- C ABI of the MI355X (gfx950) render backend.
+ *
+ * This is the drop-in boundary for ONE call of the reference ray tracer:
+ *
+ *     impl Camera { pub fn render(&self, world: &World) -> Canvas }   (src/camera.rs:74-88)
+ *
+ * and everything it calls (World::color_at src/world.rs:58-66 and below).  The reference has
+ * no FFI today; a Rust `-sys` crate binds exactly the functions declared here (see
+ * rust/rt355-sys/src/lib.rs).  Plain C: no exceptions cross this boundary, every function returns 0
+ * or a negative RT355_E* code, rt355_last_error() gives a thread-local message.
+ *
+ * All scalar inputs are f32 because every scalar in the reference is f32 (src/epsilon.rs:1,
+ * src/camera.rs:12-18).  The arithmetic type of the device kernels is chosen per context:
+ * real_bits = 64 (double) or 32 (float, the reference's own precision).
+ */
+#ifndef RT355_H
+#define RT355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT355_VERSION 1
+
+/* error codes */
+#define RT355_OK 0
+#define RT355_EINVAL (-1)    /* bad argument, singular / non-affine transform, NaN in the scene   */
+#define RT355_EHIP (-2)      /* a HIP runtime call failed                                          */
+#define RT355_ECAPACITY (-3) /* secondary-ray pool exhausted (raise it with rt355_ctx_set_pool)    */
+#define RT355_ENOMEM (-4)
+
+/* Shape kinds, in the order of `enum Shape` (src/shape.rs:11-20). */
+enum rt355_kind {
+  RT355_SPHERE = 0,
+  RT355_PLANE = 1,
+  RT355_CUBE = 2,
+  RT355_CYLINDER = 3,
+  RT355_CONE = 4,
+  RT355_GROUP = 5, /* inert inside a World (src/shape.rs:376, :134, :204): never hit */
+  RT355_TRIANGLE = 6,
+  RT355_SMOOTH_TRIANGLE = 7
+};
+
+/* Pattern kinds, in the order of `enum Pattern` (src/pattern.rs:6-12); 0 = material.pattern None. */
+enum rt355_pattern {
+  RT355_PATTERN_NONE = 0,
+  RT355_PATTERN_STRIPE = 1,
+  RT355_PATTERN_GRADIENT = 2,
+  RT355_PATTERN_RING = 3,
+  RT355_PATTERN_CHECKER = 4,
+  RT355_PATTERN_TEST = 5
+};
+
+/* `struct Material` (src/material.rs:6-17).  The pattern's own transformation is stored by the
+ * reference but never read (src/pattern.rs:16,94), so it is not part of the ABI. */
+typedef struct rt355_material {
+  float color[3];
+  float ambient, diffuse, specular, shininess;
+  float reflective, refractive, transparency;
+  int32_t pattern_kind;
+  float c1[3], c2[3];
+} rt355_material;
+
+/* One entry of `World.shapes` (src/world.rs:17-20).  The array index IS the shape id used for
+ * nearest-hit ties (lowest index wins: stable sort src/world.rs:42 + first-min
+ * src/intersection.rs:151) and reported by rt355_trace_sample. */
+typedef struct rt355_shape_desc {
+  int32_t kind;      /* enum rt355_kind */
+  float m[16];       /* `transformation`, column-major as nalgebra stores Matrix4<f32> */
+  rt355_material mat;
+  float min, max;    /* cylinder / cone extents (src/cylinder.rs:11-13); +-INFINITY allowed */
+  int32_t closed;
+  float p1[3], p2[3], p3[3]; /* triangle / smooth triangle vertices (src/triangle.rs:10-12) */
+  float n1[3], n2[3], n3[3]; /* smooth triangle vertex normals (src/smooth_triangle.rs:16-18) */
+} rt355_shape_desc;
+
+/* `struct PointLight` (src/pointlight.rs:7-10). */
+typedef struct rt355_light_desc {
+  float position[3];
+  float intensity[3];
+} rt355_light_desc;
+
+/* The three public arguments of Camera::new plus its transform (src/camera.rs:23-28); half_width,
+ * half_height and pixel_size are re-derived inside the library exactly as src/camera.rs:29-41. */
+typedef struct rt355_camera_desc {
+  float hsize, vsize, fov;
+  float transform[16]; /* column-major */
+} rt355_camera_desc;
+
+#define RT355_MAX_GEN 8     /* generations 0..max_depth; max_depth <= 7 */
+#define RT355_MAX_LAUNCH 32 /* per-frame kernel launches recorded in rt355_stats */
+
+/* Kernel classes recorded per launch in rt355_stats.launch_kind. */
+enum rt355_launch_kind {
+  RT355_K_TRACE = 1,   /* nearest-hit traversal (generation 0 also generates the primary rays) */
+  RT355_K_SHADE = 2,   /* precompute + n1/n2 + shadow ray + Phong + child-ray spawn            */
+  RT355_K_COMBINE = 3, /* child colours folded into their parent, last pass writes the canvas  */
+  RT355_K_CLEAR = 4
+};
+
+/* Per-frame statistics.  Ray counts are always filled.  Work counters (box_tests ... flops) are
+ * filled only when the context is in counting mode (rt355_ctx_set_counting), which runs
+ * instrumented kernels and is not meant to be timed.  Launch times are filled when timing mode
+ * is on (rt355_ctx_set_timing): HIP events around every launch on the context's stream. */
+typedef struct rt355_stats {
+  uint64_t radiance_rays[RT355_MAX_GEN]; /* one per color_at call (src/world.rs:58)      */
+  uint64_t hits[RT355_MAX_GEN];          /* = shadow rays: one per is_shadowed call (:105) */
+  uint64_t total_radiance, total_shadow;
+  double frame_ms;                       /* host wall time of the call, device-synchronised */
+  int32_t n_launch;
+  int32_t launch_kind[RT355_MAX_LAUNCH];
+  int32_t launch_gen[RT355_MAX_LAUNCH];
+  float launch_ms[RT355_MAX_LAUNCH];
+  /* counting mode, per launch */
+  uint64_t launch_box_tests[RT355_MAX_LAUNCH];  /* child-box slab tests               */
+  uint64_t launch_prim_tests[RT355_MAX_LAUNCH]; /* local_intersect calls, all kinds    */
+  double launch_flops[RT355_MAX_LAUNCH];        /* algorithmic FLOPs, see rt355_flop_table */
+} rt355_stats;
+
+typedef struct rt355_ctx rt355_ctx;     /* one device, one stream, scratch pools */
+typedef struct rt355_scene rt355_scene; /* device-resident shape tables + BVH    */
+
+const char* rt355_last_error(void);
+int rt355_version(void);
+
+/* One context per (process, GPU).  real_bits: 64 or 32. */
+int rt355_ctx_create(rt355_ctx** out, int device_id, int real_bits);
+void rt355_ctx_destroy(rt355_ctx*);
+/* Secondary-ray pool capacity in rays per primary ray (default 4.0). */
+int rt355_ctx_set_pool(rt355_ctx*, double rays_per_pixel);
+int rt355_ctx_set_counting(rt355_ctx*, int on);
+int rt355_ctx_set_timing(rt355_ctx*, int on);
+
+/* Replaces the per-ray work the reference redoes for every shape and every ray
+ * (Ray::inv_transform src/ray.rs:32-37, Shape::normal src/shape.rs:111-136): inverses, triangle
+ * edges and flat normals (src/triangle.rs:65-66,83-85) and the BVH are built here, ONCE.
+ * Group entries are kept as index placeholders and never hit. */
+int rt355_scene_upload(rt355_ctx*, const rt355_shape_desc* shapes, size_t n_shapes,
+                       const rt355_light_desc* light, rt355_scene** out);
+void rt355_scene_destroy(rt355_scene*);
+/* BVH facts for reports: out[0]=nodes, out[1]=bounded prims, out[2]=unbounded prims,
+ * out[3]=max depth, out[4]=device bytes. */
+int rt355_scene_info(const rt355_scene*, uint64_t out[5]);
+
+/* Camera::render (src/camera.rs:74-88).  rgb_out: hsize*vsize*3 floats, caller-owned HOST memory,
+ * row-major from the top-left, unclamped linear RGB, like Canvas.pixels (src/canvas.rs:8-12).
+ * max_depth is the constant 5 of src/camera.rs:79. */
+int rt355_render(rt355_ctx*, const rt355_scene*, const rt355_camera_desc* cam, int max_depth,
+                 float* rgb_out, rt355_stats* stats /* nullable */);
+
+/* Same frame, rank `rank` of `n_ranks` renders only its 32x32 tiles (tile t belongs to rank
+ * t % n_ranks) into DEVICE memory `tiles_out`: rt355_tiles_per_rank() * 1024 * 3 floats, tile-major,
+ * pixels of a tile row-major.  With n_ranks == 1 this is the whole frame in tile order.
+ * The call is synchronous with respect to the host. */
+int rt355_render_tiles(rt355_ctx*, const rt355_scene*, const rt355_camera_desc* cam, int max_depth,
+                       int rank, int n_ranks, float* tiles_out_dev, rt355_stats* stats);
+/* Number of tiles each rank owns (tile count padded up to a multiple of n_ranks). */
+int64_t rt355_tiles_per_rank(const rt355_camera_desc* cam, int n_ranks);
+/* Rank 0, after the gather: `gathered_dev` holds n_ranks consecutive rank buffers; scatters them
+ * to the row-major canvas `rgb_out_dev` (hsize*vsize*3 floats, device memory). */
+int rt355_untile(rt355_ctx*, const rt355_camera_desc* cam, int n_ranks, const float* gathered_dev,
+                 float* rgb_out_dev);
+
+/* World::color_at(ray, max_depth) (src/world.rs:58-66) for caller-supplied rays: rays is n*6
+ * floats (origin xyz, direction xyz; direction is used as given, not normalised), rgb_out n*3. */
+int rt355_color_at(rt355_ctx*, const rt355_scene*, const float* rays, size_t n, int max_depth,
+                   float* rgb_out, rt355_stats* stats);
+
+/* Parity probe: World::intersect + Intersections::hit (src/world.rs:35-44,
+ * src/intersection.rs:149-154) for n rays.  t_out[i] = nearest t >= 0 (NaN when there is no hit),
+ * shape_index_out[i] = index into the uploaded shape array (-1 when there is no hit). */
+int rt355_trace_sample(rt355_ctx*, const rt355_scene*, const float* rays /* n*6 */, size_t n,
+                       double* t_out, int32_t* shape_index_out);
+
+/* Parity probe: World::is_shadowed (src/world.rs:45-57) for n points (n*3 floats). */
+int rt355_is_shadowed(rt355_ctx*, const rt355_scene*, const float* points, size_t n,
+                      uint8_t* out);
+
+/* Color::to_u8 (src/color.rs:97-111) on the device: n floats -> n bytes, both HOST memory. */
+int rt355_to_u8(rt355_ctx*, const float* rgb, size_t n, uint8_t* out);
+
+/* Algorithmic FLOP weights used for launch_flops: out[0]=primary ray, [1]=box test,
+ * [2]=ray->object transform, [3..10]=local_intersect per rt355_kind, [11]=shading per hit,
+ * [12]=reflect spawn, [13]=refract spawn, [14]=schlick. */
+void rt355_flop_table(double out[16]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT355_H */
