@@ -130,8 +130,15 @@ int rt355_version(void);
 /* One context per (process, GPU).  real_bits: 64 or 32. */
 int rt355_ctx_create(rt355_ctx** out, int device_id, int real_bits);
 void rt355_ctx_destroy(rt355_ctx*);
-/* Secondary-ray pool capacity in rays per primary ray (default 4.0). */
+/* Ray pool capacity in rays (all generations) per primary ray (default 8.0). */
 int rt355_ctx_set_pool(rt355_ctx*, double rays_per_pixel);
+/* A truncated cone hit by a ray that is parallel to one of its halves (|a| <= EPSILON at
+ * src/shape.rs:295-298) is reported by the reference WITHOUT the min < y < max test, i.e. anywhere on the
+ * infinite double cone.  Such hits have no finite bound.  mode 1: every truncated cone is tested by
+ * every ray (exact, slow for many cones).  mode 0 (default): exact while the scene holds at most 32
+ * truncated cones; beyond that cones live in the BVH and a hit of this kind is found only if the ray
+ * also passes the cone's bounding box.  Applies to scenes uploaded afterwards. */
+int rt355_ctx_set_exact_cones(rt355_ctx*, int mode);
 int rt355_ctx_set_counting(rt355_ctx*, int on);
 int rt355_ctx_set_timing(rt355_ctx*, int on);
 

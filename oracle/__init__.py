@@ -78,16 +78,19 @@ def color_at(world, rays, depth=5, real_bits=32, flags=0):
     return out
 
 
-def hit(world, rays, real_bits=32):
+def hit(world, rays, real_bits=32, with_beyond=False):
     """Nearest hit per ray: (t float64 [NaN = miss], shape index int32 [-1 = miss], gap to the nearest
-    intersection of another shape)."""
+    intersection of another shape[, flag: truncated-cone hit outside its extent])."""
     descs, n, _ = _world_args(world)
     r = _f32(rays, 6)
     t = np.zeros(r.shape[0], dtype=np.float64)
     idx = np.zeros(r.shape[0], dtype=np.int32)
     gap = np.zeros(r.shape[0], dtype=np.float64)
-    rc = lib().rto_hit(descs, n, _p(r), C.c_size_t(r.shape[0]), real_bits, _p(t), _p(idx), _p(gap))
+    beyond = np.zeros(r.shape[0], dtype=np.uint8)
+    rc = lib().rto_hit(descs, n, _p(r), C.c_size_t(r.shape[0]), real_bits, _p(t), _p(idx), _p(gap), _p(beyond))
     assert rc == 0
+    if with_beyond:
+        return t, idx, gap, beyond.astype(bool)
     return t, idx, gap
 
 

@@ -95,7 +95,7 @@ int color_at_impl(const rt355_shape_desc* shapes, size_t n, const rt355_light_de
 
 template <class R>
 int hit_impl(const rt355_shape_desc* shapes, size_t n, const float* rays, size_t nrays, double* t_out,
-             int32_t* idx_out, double* runner_up_gap) {
+             int32_t* idx_out, double* runner_up_gap, uint8_t* beyond_extent) {
   World<R> w;
   if (!build_world<R>(shapes, n, nullptr, 0, w)) return -1;
   for (size_t i = 0; i < nrays; ++i) {
@@ -107,10 +107,20 @@ int hit_impl(const rt355_shape_desc* shapes, size_t n, const float* rays, size_t
       t_out[i] = std::numeric_limits<double>::quiet_NaN();
       idx_out[i] = -1;
       if (runner_up_gap) runner_up_gap[i] = std::numeric_limits<double>::infinity();
+      if (beyond_extent) beyond_extent[i] = 0;
       continue;
     }
     t_out[i] = xs[h].t;
     idx_out[i] = xs[h].shape;
+    if (beyond_extent) {
+      // a truncated cone hit outside min..max: the parallel-ray branch of shape.rs:295-298
+      const Shape<R>& s = w.shapes[xs[h].shape];
+      beyond_extent[i] = 0;
+      if (s.kind == RT355_CONE && std::isfinite((double)s.min) && std::isfinite((double)s.max)) {
+        V4<R> lp = s.inv * ray.position(xs[h].t);
+        if ((double)lp.y < (double)s.min - 1e-6 || (double)lp.y > (double)s.max + 1e-6) beyond_extent[i] = 1;
+      }
+    }
     if (runner_up_gap) {
       // distance in t to the nearest intersection of a DIFFERENT shape at t >= 0: marks ties
       double gap = std::numeric_limits<double>::infinity();
@@ -246,8 +256,8 @@ int rto_color_at(const rt355_shape_desc* shapes, size_t n, const rt355_light_des
   return DISPATCH(real_bits, color_at_impl, shapes, n, light, rays, nrays, depth, flags, rgb_out);
 }
 int rto_hit(const rt355_shape_desc* shapes, size_t n, const float* rays, size_t nrays, int real_bits,
-            double* t_out, int32_t* idx_out, double* runner_up_gap) {
-  return DISPATCH(real_bits, hit_impl, shapes, n, rays, nrays, t_out, idx_out, runner_up_gap);
+            double* t_out, int32_t* idx_out, double* runner_up_gap, uint8_t* beyond_extent) {
+  return DISPATCH(real_bits, hit_impl, shapes, n, rays, nrays, t_out, idx_out, runner_up_gap, beyond_extent);
 }
 int rto_world_intersect(const rt355_shape_desc* shapes, size_t n, const float* ray, int real_bits,
                         double* t_out, int32_t* idx_out, int cap) {

@@ -84,6 +84,7 @@ SYMBOLS = [
     ("rt355_ctx_create", C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
     ("rt355_ctx_destroy", None, [C.c_void_p]),
     ("rt355_ctx_set_pool", C.c_int, [C.c_void_p, C.c_double]),
+    ("rt355_ctx_set_exact_cones", C.c_int, [C.c_void_p, C.c_int]),
     ("rt355_ctx_set_counting", C.c_int, [C.c_void_p, C.c_int]),
     ("rt355_ctx_set_timing", C.c_int, [C.c_void_p, C.c_int]),
     ("rt355_scene_upload", C.c_int, [C.c_void_p, C.POINTER(ShapeDesc), C.c_size_t, C.POINTER(LightDesc), C.POINTER(C.c_void_p)]),
@@ -112,6 +113,13 @@ def lib():
         raise RuntimeError(
             f"HIP backend not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'`."
         )
+    # PyTorch wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Two HIP runtimes in
+    # one process do not work, and the one that is loaded first wins the SONAME: import torch first so
+    # that this library binds to torch's runtime whenever both live in one process.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     l = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
         fn = getattr(l, name)  # AttributeError if the library does not export it

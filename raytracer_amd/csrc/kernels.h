@@ -1,0 +1,793 @@
+// kernels.h -- HIP kernels of the wavefront render pipeline (gfx950, wave64).
+//
+// The reference renders a pixel by recursion: Camera::render -> World::color_at -> shade_hit ->
+// is_shadowed / reflected_color / refracted_color -> color_at ... (src/camera.rs:74-88,
+// src/world.rs:58-127).  Here the recursion is unrolled into GENERATIONS of rays (generation g holds the
+// rays whose `remaining` is max_depth - g) and each generation runs three data-parallel kernels:
+//
+//   k_trace    World::intersect + Intersections::hit        one thread per ray, BVH traversal
+//   k_shade    prepare_computation + is_shadowed + lighting  one thread per HIT, spawns child rays into
+//              + reflect / refract / schlick                 generation g+1 (wave64 ballot compaction)
+//   k_combine  shade_hit's final sum                          run from the deepest generation back to 0
+//
+// Every hit keeps its own record (surface colour, the two child ids, the mix weights), so k_combine
+// evaluates exactly the reference's expression  surface + reflected*R + refracted*(1-R)  (or
+// surface + refracted + reflected) per hit, in the reference's order, with no atomics on colours: the
+// image does not depend on queue order and is bit-identical across tile splits.
+//
+// Arithmetic follows the reference expression by expression (file:line cited at each function),
+// templated on the scalar type R (double = graded configuration, float = the reference's precision).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rt355_device.h"
+
+namespace rt355 {
+
+// ------------------------------------------------------------------------------------------------
+// small vector helpers
+// ------------------------------------------------------------------------------------------------
+template <class R>
+struct V3 {
+  R x, y, z;
+};
+#define RT_FN __device__ __forceinline__
+template <class R> RT_FN V3<R> mk(R x, R y, R z) { return V3<R>{x, y, z}; }
+template <class R> RT_FN V3<R> operator+(V3<R> a, V3<R> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <class R> RT_FN V3<R> operator-(V3<R> a, V3<R> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <class R> RT_FN V3<R> operator*(V3<R> a, R k) { return {a.x * k, a.y * k, a.z * k}; }
+template <class R> RT_FN V3<R> operator*(R k, V3<R> a) { return {a.x * k, a.y * k, a.z * k}; }
+template <class R> RT_FN R dot(V3<R> a, V3<R> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class R> RT_FN V3<R> cross(V3<R> a, V3<R> b) {  // src/tuple.rs:42-48
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+template <class R> RT_FN V3<R> normalize(V3<R> a) {  // nalgebra: no zero guard
+  R n = sqrt(dot(a, a));
+  return {a.x / n, a.y / n, a.z / n};
+}
+template <class R> RT_FN V3<R> reflect(V3<R> v, V3<R> n) {  // src/tuple.rs:38-40
+  return v - n * R(2) * dot(v, n);
+}
+template <class R> RT_FN V3<R> ld3(const R* p) { return {p[0], p[1], p[2]}; }
+template <class R> RT_FN void st3(R* p, V3<R> v) { p[0] = v.x, p[1] = v.y, p[2] = v.z; }
+
+template <class R> RT_FN R eps() { return R(1.0e-3); }  // src/epsilon.rs:1
+template <class R> RT_FN R inf() { return R(INFINITY); }
+
+// approx::relative_eq!(x, 0., epsilon = EPSILON) (call sites src/shape.rs:252,295,296,331,355,484,498):
+// true for |x| <= EPSILON, false for infinities and NaN.
+template <class R> RT_FN bool approx_zero(R x) { return fabs(x) <= eps<R>(); }
+
+// rows 0..2 of an affine inverse applied to a point / a vector (src/ray.rs:32-37)
+template <class R> RT_FN V3<R> xf_point(const R* r, V3<R> p) {
+  return {r[0] * p.x + r[1] * p.y + r[2] * p.z + r[3], r[4] * p.x + r[5] * p.y + r[6] * p.z + r[7],
+          r[8] * p.x + r[9] * p.y + r[10] * p.z + r[11]};
+}
+template <class R> RT_FN V3<R> xf_vec(const R* r, V3<R> v) {
+  return {r[0] * v.x + r[1] * v.y + r[2] * v.z, r[4] * v.x + r[5] * v.y + r[6] * v.z,
+          r[8] * v.x + r[9] * v.y + r[10] * v.z};
+}
+
+struct Work {  // per-thread work counters (counting mode only)
+  uint32_t box = 0, xf = 0, prim[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+template <bool COUNT> RT_FN void flush_work(FrameCtl* ctl, int launch, const Work& w) {
+  if constexpr (COUNT) {
+    if (w.box) atomicAdd(&ctl->work[launch][0], (unsigned long long)w.box);
+    if (w.xf) atomicAdd(&ctl->work[launch][1], (unsigned long long)w.xf);
+    for (int k = 0; k < 8; ++k)
+      if (w.prim[k]) atomicAdd(&ctl->work[launch][2 + k], (unsigned long long)w.prim[k]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Shape::intersect = local_intersect(ray.inv_transform(transformation))  (src/shape.rs:208-415)
+// emit(t, u, v, emission_index) is called once per intersection, in the reference's emission order.
+// ------------------------------------------------------------------------------------------------
+template <class R, bool COUNT, class Emit>
+RT_FN void prim_hits(const DevScene<R>& sc, int p, int flags, V3<R> wo, V3<R> wd, Work& wk, Emit&& emit) {
+  const int kind = flags & PF_KIND_MASK;
+  if constexpr (COUNT) wk.prim[kind]++;
+  V3<R> o = wo, d = wd;
+  if (!(flags & PF_IDENTITY)) {
+    const R* r = sc.xform[p].r;
+    o = xf_point(r, wo);
+    d = xf_vec(r, wd);
+    if constexpr (COUNT) wk.xf++;
+  }
+  const R EPS = eps<R>();
+  if (kind >= RT355_TRIANGLE) {
+    // src/shape.rs:328-375 (Moeller-Trumbore)
+    const DevTri<R>& T = sc.tri[p];
+    V3<R> e1 = ld3(T.e1), e2 = ld3(T.e2), p1 = ld3(T.p1);
+    V3<R> dir_cross_e2 = cross(d, e2);
+    R det = dot(e1, dir_cross_e2);
+    if (approx_zero(fabs(det))) return;
+    R f = R(1) / det;
+    V3<R> p1_to_origin = o - p1;
+    R u = f * dot(p1_to_origin, dir_cross_e2);
+    if (u < R(0) || u > R(1)) return;
+    V3<R> origin_cross_e1 = cross(p1_to_origin, e1);
+    R v = f * dot(d, origin_cross_e1);
+    if (v < R(0) || (u + v) > R(1)) return;
+    R t = f * dot(e2, origin_cross_e1);
+    emit(t, u, v, 0);
+    return;
+  }
+  switch (kind) {
+    case RT355_PLANE: {  // src/shape.rs:210-217
+      if (fabs(d.y) < EPS) return;
+      emit(-o.y / d.y, R(0), R(0), 0);
+      return;
+    }
+    case RT355_SPHERE: {  // src/shape.rs:218-233
+      R a = dot(d, d);
+      R b = R(2) * dot(d, o);
+      R c = dot(o, o) - R(1);
+      R disc = b * b - R(4) * a * c;
+      if (disc < R(0)) return;
+      R sq = sqrt(disc);
+      emit((-b - sq) / (R(2) * a), R(0), R(0), 0);
+      emit((-b + sq) / (R(2) * a), R(0), R(0), 1);
+      return;
+    }
+    case RT355_CUBE: {  // src/shape.rs:234-248, 455-466
+      R t0x, t1x, t0y, t1y, t0z, t1z;
+      if (d.x >= R(0)) { t0x = (R(-1) - o.x) / d.x; t1x = (R(1) - o.x) / d.x; } else { t1x = (R(-1) - o.x) / d.x; t0x = (R(1) - o.x) / d.x; }
+      if (d.y >= R(0)) { t0y = (R(-1) - o.y) / d.y; t1y = (R(1) - o.y) / d.y; } else { t1y = (R(-1) - o.y) / d.y; t0y = (R(1) - o.y) / d.y; }
+      if (d.z >= R(0)) { t0z = (R(-1) - o.z) / d.z; t1z = (R(1) - o.z) / d.z; } else { t1z = (R(-1) - o.z) / d.z; t0z = (R(1) - o.z) / d.z; }
+      R tmin = fmax(fmax(t0x, t0y), t0z);
+      R tmax = fmin(fmin(t1x, t1y), t1z);
+      if (tmin > tmax) return;
+      emit(tmin, R(0), R(0), 0);
+      emit(tmax, R(0), R(0), 1);
+      return;
+    }
+    case RT355_CYLINDER:
+    case RT355_CONE: {  // src/shape.rs:249-327, caps 468-514
+      const R ymin = sc.xform[p].ymin, ymax = sc.xform[p].ymax;
+      const bool cone = kind == RT355_CONE;
+      int em = 0;
+      bool walls_done = false;
+      if (!cone) {
+        R a = d.x * d.x + d.z * d.z;
+        if (!approx_zero(a)) {
+          R b = R(2) * o.x * d.x + R(2) * o.z * d.z;
+          R c = o.x * o.x + o.z * o.z - R(1);
+          R disc = b * b - R(4) * a * c;
+          if (disc < R(0)) return;  // returns before the caps are tried (src/shape.rs:260-262)
+          R t0 = (-b - sqrt(disc)) / (R(2) * a);
+          R t1 = (-b + sqrt(disc)) / (R(2) * a);
+          if (t0 > t1) { R s = t0; t0 = t1; t1 = s; }
+          R y0 = o.y + t0 * d.y;
+          if (ymin < y0 && y0 < ymax) emit(t0, R(0), R(0), em++);
+          R y1 = o.y + t1 * d.y;
+          if (ymin < y1 && y1 < ymax) emit(t1, R(0), R(0), em++);
+        }
+        walls_done = true;
+      } else {
+        R a = d.x * d.x - d.y * d.y + d.z * d.z;
+        R b = R(2) * (o.x * d.x - o.y * d.y + o.z * d.z);
+        R c = o.x * o.x - o.y * o.y + o.z * o.z;
+        if (approx_zero(a) && !approx_zero(b)) {
+          emit(c / (R(-2) * b), R(0), R(0), em++);
+        } else {
+          // discriminant rounded to two decimals before the sign test (src/shape.rs:300)
+          R disc = round((b * b - R(4) * a * c) * R(100)) / R(100);
+          if (disc < R(0)) return;
+          R t0 = (-b - sqrt(disc)) / (R(2) * a);
+          R t1 = (-b + sqrt(disc)) / (R(2) * a);
+          if (t0 > t1) { R s = t0; t0 = t1; t1 = s; }
+          R y0 = o.y + t0 * d.y;
+          if (ymin < y0 && y0 < ymax) emit(t0, R(0), R(0), em++);
+          R y1 = o.y + t1 * d.y;
+          if (ymin < y1 && y1 < ymax) emit(t1, R(0), R(0), em++);
+        }
+        walls_done = true;
+      }
+      (void)walls_done;
+      // intersect_caps (src/shape.rs:480-514)
+      if (!(flags & PF_CLOSED) || approx_zero(d.y)) return;
+      R t_lower = (ymin - o.y) / d.y;
+      R t_upper = (ymax - o.y) / d.y;
+      R rl = cone ? ymin * ymin : R(1), ru = cone ? ymax * ymax : R(1);
+      {
+        R x = o.x + t_lower * d.x, z = o.z + t_lower * d.z;
+        if (x * x + z * z <= rl + EPS) emit(t_lower, R(0), R(0), em++);
+      }
+      {
+        R x = o.x + t_upper * d.x, z = o.z + t_upper * d.z;
+        if (x * x + z * z <= ru + EPS) emit(t_upper, R(0), R(0), em++);
+      }
+      return;
+    }
+    default:
+      return;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BVH traversal.  Visitor: tmin(), tmax() give the live ray interval; prim(p) tests one prim and returns
+// true to stop.  Replaces the brute-force loop of World::intersect (src/world.rs:35-44).
+// ------------------------------------------------------------------------------------------------
+template <class R, bool COUNT, class Vis>
+RT_FN void traverse(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work& wk) {
+  for (int p = sc.n_bounded; p < sc.n_prims; ++p)
+    if (vis.prim(p)) return;
+  if (sc.n_nodes == 0) return;
+  const V3<R> id = {R(1) / d.x, R(1) / d.y, R(1) / d.z};
+  int stack[STACK_DEPTH];
+  int sp = 0;
+  int cur = 0;
+  for (;;) {
+    if (cur >= 0) {
+      const BvhNode<R>& N = sc.nodes[cur];
+      const R tmin = vis.tmin(), tmax = vis.tmax();
+      R ax0 = (N.lo0[0] - o.x) * id.x, ax1 = (N.hi0[0] - o.x) * id.x;
+      R ay0 = (N.lo0[1] - o.y) * id.y, ay1 = (N.hi0[1] - o.y) * id.y;
+      R az0 = (N.lo0[2] - o.z) * id.z, az1 = (N.hi0[2] - o.z) * id.z;
+      R an = fmax(fmax(fmin(ax0, ax1), fmin(ay0, ay1)), fmax(fmin(az0, az1), tmin));
+      R af = fmin(fmin(fmax(ax0, ax1), fmax(ay0, ay1)), fmin(fmax(az0, az1), tmax));
+      R bx0 = (N.lo1[0] - o.x) * id.x, bx1 = (N.hi1[0] - o.x) * id.x;
+      R by0 = (N.lo1[1] - o.y) * id.y, by1 = (N.hi1[1] - o.y) * id.y;
+      R bz0 = (N.lo1[2] - o.z) * id.z, bz1 = (N.hi1[2] - o.z) * id.z;
+      R bn = fmax(fmax(fmin(bx0, bx1), fmin(by0, by1)), fmax(fmin(bz0, bz1), tmin));
+      R bf = fmin(fmin(fmax(bx0, bx1), fmax(by0, by1)), fmin(fmax(bz0, bz1), tmax));
+      const bool ha = an <= af, hb = bn <= bf;
+      const int c0 = N.c0, c1 = N.c1;
+      if constexpr (COUNT) wk.box += 2;
+      if (ha && hb) {
+        const bool a_first = an <= bn;
+        stack[sp++] = a_first ? c1 : c0;
+        cur = a_first ? c0 : c1;
+        continue;
+      }
+      if (ha) { cur = c0; continue; }
+      if (hb) { cur = c1; continue; }
+    } else {
+      const uint32_t leaf = (uint32_t)~cur;
+      const int first = (int)(leaf & 0x3FFFFFFu), count = (int)(leaf >> 26);
+      for (int k = 0; k < count; ++k)
+        if (vis.prim(first + k)) return;
+    }
+    if (sp == 0) return;
+    cur = stack[--sp];
+  }
+}
+
+// Nearest hit with t >= 0; among equal t the lowest shape index wins (stable sort src/world.rs:42 +
+// first minimum src/intersection.rs:151).  NaN t never qualifies.
+template <class R, bool COUNT>
+struct ClosestVis {
+  const DevScene<R>& sc;
+  V3<R> o, d;
+  Work& wk;
+  R best_t, best_u, best_v;
+  int best_p, best_s;
+  RT_FN ClosestVis(const DevScene<R>& s, V3<R> o_, V3<R> d_, Work& w)
+      : sc(s), o(o_), d(d_), wk(w), best_t(inf<R>()), best_u(0), best_v(0), best_p(-1), best_s(0x7fffffff) {}
+  RT_FN R tmin() const { return R(0); }
+  RT_FN R tmax() const { return best_t; }
+  RT_FN bool prim(int p) {
+    const PrimInfo info = sc.prim_info[p];
+    prim_hits<R, COUNT>(sc, p, info.flags, o, d, wk, [&](R t, R u, R v, int) {
+      if (t >= R(0) && (t < best_t || (t == best_t && info.shape < best_s))) {
+        best_t = t, best_u = u, best_v = v, best_p = p, best_s = info.shape;
+      }
+    });
+    return false;
+  }
+};
+
+// is_shadowed: some intersection with 0 <= t < limit (src/world.rs:45-57; limit = distance + EPSILON).
+template <class R, bool COUNT>
+struct AnyVis {
+  const DevScene<R>& sc;
+  V3<R> o, d;
+  Work& wk;
+  R limit;
+  bool found;
+  RT_FN AnyVis(const DevScene<R>& s, V3<R> o_, V3<R> d_, R lim, Work& w) : sc(s), o(o_), d(d_), wk(w), limit(lim), found(false) {}
+  RT_FN R tmin() const { return R(0); }
+  RT_FN R tmax() const { return limit; }
+  RT_FN bool prim(int p) {
+    const PrimInfo info = sc.prim_info[p];
+    prim_hits<R, COUNT>(sc, p, info.flags, o, d, wk, [&](R t, R, R, int) {
+      if (t >= R(0) && t < limit) found = true;
+    });
+    return found;
+  }
+};
+
+// n1/n2 of prepare_computation (src/intersection.rs:86-127) without materialising the sorted list.
+// The reference walks the sorted intersections and toggles shapes in a container: a shape is present
+// after an odd number of its intersections, and the container's last element is the present shape whose
+// latest intersection comes last in the sorted order.  So it is enough to keep, over every OTHER shape
+// with an odd number of intersections sorted before the hit, the one whose latest such intersection has
+// the largest (t, shape index) key.
+template <class R, bool COUNT>
+struct ContainerVis {
+  const DevScene<R>& sc;
+  V3<R> o, d;
+  Work& wk;
+  R t_hit;
+  int s_hit, p_hit;
+  bool have;
+  R bt;
+  int bs, bflags;
+  RT_FN ContainerVis(const DevScene<R>& s, V3<R> o_, V3<R> d_, R th, int sh, int ph, Work& w)
+      : sc(s), o(o_), d(d_), wk(w), t_hit(th), s_hit(sh), p_hit(ph), have(false), bt(0), bs(-1), bflags(0) {}
+  RT_FN R tmin() const { return -inf<R>(); }
+  RT_FN R tmax() const { return t_hit; }
+  RT_FN bool prim(int p) {
+    if (p == p_hit) return false;
+    const PrimInfo info = sc.prim_info[p];
+    int cnt = 0;
+    R mt = R(0);
+    prim_hits<R, COUNT>(sc, p, info.flags, o, d, wk, [&](R t, R, R, int) {
+      if (t < t_hit || (t == t_hit && info.shape < s_hit)) {
+        if (cnt == 0 || t > mt) mt = t;
+        ++cnt;
+      }
+    });
+    if (cnt & 1) {
+      if (!have || mt > bt || (mt == bt && info.shape > bs)) have = true, bt = mt, bs = info.shape, bflags = info.flags;
+    }
+    return false;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// wave64 compaction: every active lane asks for `want` (0/1) slots of one kind and `want2` of another;
+// one atomic per wave.  Returns the wave's base; offsets are positions inside the wave's block.
+// ------------------------------------------------------------------------------------------------
+RT_FN uint32_t wave_alloc2(uint32_t* counter, bool want, bool want2, uint32_t& off1, uint32_t& off2) {
+  const unsigned long long m1 = __ballot(want), m2 = __ballot(want2), act = __ballot(1);
+  const int lane = __lane_id();
+  const int leader = __ffsll((long long)act) - 1;
+  const uint32_t n1 = __popcll(m1), n2 = __popcll(m2);
+  uint32_t base = 0;
+  if (lane == leader && (n1 + n2)) base = atomicAdd(counter, n1 + n2);
+  base = __shfl(base, leader);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  off1 = __popcll(m1 & lt);
+  off2 = n1 + __popcll(m2 & lt);
+  return base;
+}
+
+// Id range of generation `gen`: generations are stacked in the pool in order.  A generation that did
+// not fit is cut at the pool's capacity (the frame is then reported as RT355_ECAPACITY).
+RT_FN void gen_range(const FrameCtl* ctl, int gen, long long capacity, uint32_t& start, uint32_t& count) {
+  unsigned long long s = 0;
+  for (int g = 0; g < gen; ++g) s += ctl->gen_count[g];
+  unsigned long long c = ctl->gen_count[gen];
+  if (s > (unsigned long long)capacity) s = capacity;
+  if (s + c > (unsigned long long)capacity) c = capacity - s;
+  start = (uint32_t)s, count = (uint32_t)c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Primary rays: Camera::ray_for_pixel (src/camera.rs:62-72) with the inverse hoisted out of the pixel
+// loop.  Ray i of generation 0 is pixel (x,y) of this rank's tile list: 8x8 pixel blocks per wave.
+// ------------------------------------------------------------------------------------------------
+template <class R>
+RT_FN bool pixel_of(const DevCamera<R>& cam, uint32_t i, int& x, int& y, int& tile_local, int& in_tile) {
+  tile_local = (int)(i / TILE_PIX);
+  const int j = (int)(i % TILE_PIX);
+  const int blk = j >> 6, lane = j & 63;
+  const int xt = (blk & 3) * 8 + (lane & 7), yt = (blk >> 2) * 8 + (lane >> 3);
+  in_tile = yt * TILE + xt;
+  const long long tile = (long long)tile_local * cam.n_ranks + cam.rank;
+  if (tile >= cam.n_tiles) return false;
+  x = (int)(tile % cam.tiles_x) * TILE + xt;
+  y = (int)(tile / cam.tiles_x) * TILE + yt;
+  return x < cam.width && y < cam.height;
+}
+
+template <class R>
+__global__ void __launch_bounds__(256) k_gen_primary(DevCamera<R> cam, RayPool<R> pool, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int x, y, tl, it;
+  V3<R> org = {R(0), R(0), R(0)}, dir = {R(0), R(0), R(0)};  // zero direction = inactive ray
+  if (pixel_of(cam, i, x, y, tl, it)) {
+    const R x_offset = (R(x) + R(0.5)) * cam.pixel_size;
+    const R y_offset = (R(y) + R(0.5)) * cam.pixel_size;
+    const R world_x = cam.half_width - x_offset;
+    const R world_y = cam.half_height - y_offset;
+    const V3<R> pixel = xf_point(cam.inv, mk<R>(world_x, world_y, R(-1)));
+    org = xf_point(cam.inv, mk<R>(R(0), R(0), R(0)));
+    dir = normalize(pixel - org);
+  }
+  st3(pool.org + 3ull * i, org);
+  st3(pool.dir + 3ull * i, dir);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_trace: World::intersect + hit() for every ray of generation `gen`.
+// ------------------------------------------------------------------------------------------------
+template <class R, bool COUNT>
+__global__ void __launch_bounds__(256) k_trace(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int launch) {
+  uint32_t start, count;
+  gen_range(ctl, gen, pool.capacity, start, count);
+  const uint32_t stride = gridDim.x * blockDim.x;
+  Work wk;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+    const uint32_t r = start + i;
+    const V3<R> o = ld3(pool.org + 3ull * r), d = ld3(pool.dir + 3ull * r);
+    ClosestVis<R, COUNT> vis(sc, o, d, wk);
+    const bool live = !(d.x == R(0) && d.y == R(0) && d.z == R(0));
+    if (live) traverse<R, COUNT>(sc, o, d, vis, wk);
+    const bool hit = vis.best_p >= 0;
+    pool.hit_prim[r] = vis.best_p;
+    if (hit) {
+      pool.hit_t[r] = vis.best_t;
+      pool.hit_uv[2ull * r] = vis.best_u;
+      pool.hit_uv[2ull * r + 1] = vis.best_v;
+    } else {
+      st3(pool.color + 3ull * r, mk<R>(R(0), R(0), R(0)));  // world.rs:61-63: a miss is black
+    }
+    uint32_t off, off2;
+    const uint32_t base = wave_alloc2(&ctl->hit_count[gen], hit, false, off, off2);
+    if (hit) pool.hitlist[start + base + off] = (int32_t)r;
+  }
+  flush_work<COUNT>(ctl, launch, wk);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Shading helpers
+// ------------------------------------------------------------------------------------------------
+// Shape::normal / local_normal (src/shape.rs:111-206).  Only the sphere's normal is taken back to world
+// space and normalised; every other shape returns its object-space normal as is, unnormalised for cube /
+// cylinder side / cone side.
+template <class R>
+RT_FN V3<R> normal_at(const DevScene<R>& sc, int p, int flags, V3<R> point, R u, R v) {
+  const int kind = flags & PF_KIND_MASK;
+  const R EPS = eps<R>();
+  if (kind == RT355_SMOOTH_TRIANGLE) {
+    const DevTriNormals<R>& N = sc.trin[p];
+    return normalize(ld3(N.n2) * u + ld3(N.n3) * v + ld3(N.n1) * (R(1) - u - v));
+  }
+  if (kind == RT355_TRIANGLE) return ld3(sc.trin[p].nf);
+  if (kind == RT355_PLANE) return mk<R>(R(0), R(1), R(0));
+  const DevXform<R>& X = sc.xform[p];
+  const V3<R> lp = xf_point(X.r, point);
+  switch (kind) {
+    case RT355_SPHERE: {
+      const R* r = X.r;  // transpose(inverse) * local_point, xyz only
+      V3<R> n = {r[0] * lp.x + r[4] * lp.y + r[8] * lp.z, r[1] * lp.x + r[5] * lp.y + r[9] * lp.z,
+                 r[2] * lp.x + r[6] * lp.y + r[10] * lp.z};
+      return normalize(n);
+    }
+    case RT355_CUBE: {
+      const R ax = fabs(lp.x), ay = fabs(lp.y), az = fabs(lp.z);
+      const R maxc = fmax(fmax(ax, ay), az);
+      if (maxc == ax) return mk<R>(lp.x, R(0), R(0));
+      if (maxc == ay) return mk<R>(R(0), lp.y, R(0));
+      return mk<R>(R(0), R(0), lp.z);
+    }
+    case RT355_CYLINDER: {
+      const R dist = lp.x * lp.x + lp.z * lp.z;
+      if (dist < R(1) && lp.y >= (X.ymax - EPS)) return mk<R>(R(0), R(1), R(0));
+      if (dist < R(1) && lp.y <= (X.ymin + EPS)) return mk<R>(R(0), R(-1), R(0));
+      return mk<R>(lp.x, R(0), lp.z);
+    }
+    case RT355_CONE: {
+      const R dist = lp.x * lp.x + lp.z * lp.z;
+      if (dist < X.ymax * X.ymax && lp.y >= X.ymax - EPS) return mk<R>(R(0), R(1), R(0));
+      if (dist < X.ymin * X.ymin && lp.y <= X.ymin + EPS) return mk<R>(R(0), R(-1), R(0));
+      return mk<R>(lp.x, lp.y > R(0) ? -sqrt(dist) : sqrt(dist), lp.z);
+    }
+    default:
+      return mk<R>(R(0), R(0), R(0));
+  }
+}
+
+// Pattern::pattern_at (src/pattern.rs:93-121): evaluated on the world-space point, no transformation.
+template <class R>
+RT_FN V3<R> pattern_at(const DevMaterial<R>& m, V3<R> p) {
+  const V3<R> c1 = ld3(m.c1), c2 = ld3(m.c2);
+  switch (m.pattern_kind) {
+    case RT355_PATTERN_STRIPE:
+      return fmod(floor(p.x), R(2)) == R(0) ? c1 : c2;
+    case RT355_PATTERN_GRADIENT: {
+      const R f = p.x - floor(p.x);
+      const V3<R> dd = c2 - c1;
+      return {c1.x + f * dd.x, c1.y + f * dd.y, c1.z + f * dd.z};
+    }
+    case RT355_PATTERN_RING:
+      return floor(fmod(sqrt(p.x * p.x + p.z * p.z), R(2))) == R(0) ? c1 : c2;
+    case RT355_PATTERN_CHECKER:
+      return fmod(floor(p.x) + floor(p.y) + floor(p.z), R(2)) == R(0) ? c1 : c2;
+    case RT355_PATTERN_TEST:
+      return p;
+    default:
+      return ld3(m.color);
+  }
+}
+
+// Material::lighting (src/material.rs:108-162)
+template <class R>
+RT_FN V3<R> lighting(const DevScene<R>& sc, const DevMaterial<R>& m, V3<R> point, V3<R> eyev, V3<R> normalv, bool shadowed) {
+  const V3<R> c = m.pattern_kind != RT355_PATTERN_NONE ? pattern_at(m, point) : ld3(m.color);
+  const V3<R> li = ld3(sc.light_int);
+  const V3<R> eff = {c.x * li.x, c.y * li.y, c.z * li.z};
+  const V3<R> ambient = eff * m.ambient;
+  if (shadowed) return ambient;
+  const V3<R> lightv = normalize(ld3(sc.light_pos) - point);
+  const R ldn = dot(lightv, normalv);
+  V3<R> diffuse = {R(0), R(0), R(0)}, specular = {R(0), R(0), R(0)};
+  if (ldn >= R(0)) {
+    const R k = m.diffuse * ldn;
+    diffuse = eff * k;
+    const V3<R> rv = reflect(R(-1) * lightv, normalv);
+    const R rde = dot(rv, eyev);
+    if (rde > R(0)) {
+      const R factor = pow(rde, m.shininess);
+      specular = li * (factor * m.specular);
+    }
+  }
+  return ambient + diffuse + specular;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_shade: one thread per hit of generation `gen`.
+//   prepare_computation (src/intersection.rs:60-142), is_shadowed (src/world.rs:45-57), lighting,
+//   reflected_color / refracted_color ray set-up (src/world.rs:68-102), schlick (src/computation.rs:20-33).
+// ------------------------------------------------------------------------------------------------
+template <class R, bool COUNT>
+__global__ void __launch_bounds__(256) k_shade(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch) {
+  uint32_t start, gcount;
+  gen_range(ctl, gen, pool.capacity, start, gcount);
+  const uint32_t nhit = ctl->hit_count[gen];
+  const uint32_t child_start = start + gcount;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const R EPS = eps<R>();
+  Work wk;
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nhit; j += stride) {
+    const uint32_t r = (uint32_t)pool.hitlist[start + j];
+    const V3<R> o = ld3(pool.org + 3ull * r), d = ld3(pool.dir + 3ull * r);
+    const R t = pool.hit_t[r];
+    const int p = pool.hit_prim[r];
+    const PrimInfo info = sc.prim_info[p];
+    const DevMaterial<R>& m = sc.materials[info.flags >> PF_MAT_SHIFT];
+    const int kind = info.flags & PF_KIND_MASK;
+    R u = R(0), v = R(0);
+    if (kind == RT355_SMOOTH_TRIANGLE) u = pool.hit_uv[2ull * r], v = pool.hit_uv[2ull * r + 1];
+
+    const V3<R> point = o + d * t;  // src/ray.rs:22-24
+    const V3<R> eyev = R(-1) * d;
+    const V3<R> normalv_temp = normal_at(sc, p, info.flags, point, u, v);
+    const bool inside = dot(normalv_temp, eyev) < R(0);
+    const V3<R> normalv = inside ? R(-1) * normalv_temp : R(1) * normalv_temp;
+    const V3<R> offset = EPS * normalv;
+    const V3<R> over_point = point + offset, under_point = point - offset;
+    const V3<R> reflectv = reflect(d, normalv_temp);  // un-flipped normal (src/intersection.rs:85)
+
+    const R reflective = m.reflective, transparency = m.transparency;
+    R n1 = R(1), n2 = R(1);
+    if (transparency != R(0)) {
+      // the hit shape's own intersections, emission order
+      R ht[4];
+      int nh = 0;
+      prim_hits<R, COUNT>(sc, p, info.flags, o, d, wk, [&](R tt, R, R, int em) { if (em < 4) ht[em] = tt, nh = em + 1; });
+      // the entry the reference treats as "the hit" last: same t, latest emission
+      int m_last = 0;
+      R best = inf<R>();
+      for (int k = 0; k < 4; ++k)
+        if (k < nh) {
+          const R dd = fabs(ht[k] - t);
+          if (dd <= best) best = dd, m_last = k;
+        }
+      const R tm = nh ? ht[m_last] : t;
+      int c_before = 0;
+      R hmt = R(0);
+      for (int k = 0; k < 4; ++k)
+        if (k < nh && (ht[k] < tm || (ht[k] == tm && k < m_last))) {
+          if (c_before == 0 || ht[k] >= hmt) hmt = ht[k];
+          ++c_before;
+        }
+      ContainerVis<R, COUNT> cv(sc, o, d, t, info.shape, p, wk);
+      traverse<R, COUNT>(sc, o, d, cv, wk);
+      const R other = cv.have ? sc.materials[cv.bflags >> PF_MAT_SHIFT].refractive : R(1);
+      const bool h_before = (c_before & 1) != 0;
+      if (h_before && (!cv.have || hmt > cv.bt || (hmt == cv.bt && info.shape > cv.bs)))
+        n1 = m.refractive;
+      else
+        n1 = other;
+      n2 = ((c_before + 1) & 1) ? m.refractive : other;
+    }
+
+    // is_shadowed(over_point)
+    bool shadowed;
+    {
+      const V3<R> lv = ld3(sc.light_pos) - over_point;
+      const R distance = sqrt(dot(lv, lv));
+      const V3<R> ldir = {lv.x / distance, lv.y / distance, lv.z / distance};
+      AnyVis<R, COUNT> av(sc, over_point, ldir, distance + EPS, wk);
+      traverse<R, COUNT>(sc, over_point, ldir, av, wk);
+      shadowed = av.found;
+    }
+    const V3<R> surface = lighting(sc, m, over_point, eyev, normalv, shadowed);
+
+    // children
+    bool want_refl = remaining > 0 && reflective != R(0);
+    bool want_refr = false;
+    V3<R> refr_dir = {R(0), R(0), R(0)};
+    if (remaining > 0 && transparency != R(0)) {
+      const R n_ratio = n1 / n2;
+      const R cos_ti = dot(eyev, normalv);
+      const R sin2_t = n_ratio * n_ratio * (R(1) - cos_ti * cos_ti);
+      if (!(sin2_t > R(1))) {
+        const R cos_t = sqrt(R(1) - sin2_t);
+        refr_dir = (n_ratio * cos_ti - cos_t) * normalv - n_ratio * eyev;
+        want_refr = true;
+      }
+    }
+    R rs = R(-1);
+    if (reflective > R(0) && transparency > R(0)) {
+      R cs = dot(eyev, normalv);
+      bool tir = false;
+      if (n1 > n2) {
+        const R n = n1 / n2;
+        const R sin2_t = n * n * (R(1) - cs * cs);
+        if (sin2_t > R(1)) tir = true;
+        else cs = sqrt(R(1) - sin2_t);
+      }
+      if (tir) {
+        rs = R(1);
+      } else {
+        R r0 = (n1 - n2) / (n1 + n2);
+        r0 = r0 * r0;
+        const R k = R(1) - cs;
+        rs = r0 + ((R(1) - r0) * (k * k * k * k * k));
+      }
+    }
+
+    uint32_t off_r, off_t;
+    const uint32_t base = wave_alloc2(&ctl->gen_count[gen + 1], want_refl, want_refr, off_r, off_t);
+    int32_t child_r = -1, child_t = -1;
+    if (want_refl) {
+      const unsigned long long id = (unsigned long long)child_start + base + off_r;
+      if (id < (unsigned long long)pool.capacity) {
+        child_r = (int32_t)id;
+        st3(pool.org + 3ull * id, over_point);
+        st3(pool.dir + 3ull * id, reflectv);
+      } else {
+        ctl->overflow = 1;
+      }
+    }
+    if (want_refr) {
+      const unsigned long long id = (unsigned long long)child_start + base + off_t;
+      if (id < (unsigned long long)pool.capacity) {
+        child_t = (int32_t)id;
+        st3(pool.org + 3ull * id, under_point);
+        st3(pool.dir + 3ull * id, refr_dir);
+      } else {
+        ctl->overflow = 1;
+      }
+    }
+    st3(pool.color + 3ull * r, surface);
+    st3(pool.mix + 3ull * r, mk<R>(reflective, transparency, rs));
+    pool.child[2ull * r] = child_r;
+    pool.child[2ull * r + 1] = child_t;
+  }
+  flush_work<COUNT>(ctl, launch, wk);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_combine: shade_hit's sum (src/world.rs:117-126) for every hit of generation `gen`, deepest first.
+// ------------------------------------------------------------------------------------------------
+template <class R>
+__global__ void __launch_bounds__(256) k_combine(RayPool<R> pool, FrameCtl* ctl, int gen) {
+  uint32_t start, gcount;
+  gen_range(ctl, gen, pool.capacity, start, gcount);
+  const uint32_t nhit = ctl->hit_count[gen];
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nhit; j += stride) {
+    const uint32_t r = (uint32_t)pool.hitlist[start + j];
+    const int32_t cr = pool.child[2ull * r], ct = pool.child[2ull * r + 1];
+    if (cr < 0 && ct < 0) continue;  // colour = surface + black + black
+    const V3<R> surface = ld3(pool.color + 3ull * r);
+    const V3<R> mix = ld3(pool.mix + 3ull * r);
+    V3<R> refl = {R(0), R(0), R(0)}, refr = {R(0), R(0), R(0)};
+    if (cr >= 0) refl = ld3(pool.color + 3ull * cr) * mix.x;
+    if (ct >= 0) refr = ld3(pool.color + 3ull * ct) * mix.y;
+    V3<R> c;
+    if (mix.z >= R(0) || mix.z != mix.z)
+      c = surface + refl * mix.z + refr * (R(1) - mix.z);
+    else
+      c = surface + refr + refl;
+    st3(pool.color + 3ull * r, c);
+  }
+}
+
+enum OutMode { OUT_LINEAR = 0, OUT_ROWMAJOR = 1, OUT_TILES = 2 };
+
+// Generation-0 colours -> float canvas (Canvas.pixels, src/canvas.rs:8-12).
+template <class R>
+__global__ void __launch_bounds__(256) k_write_canvas(RayPool<R> pool, DevCamera<R> cam, uint32_t n, int mode, float* out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const V3<R> c = ld3(pool.color + 3ull * i);
+  size_t o;
+  if (mode == OUT_LINEAR) {
+    o = (size_t)i * 3;
+  } else {
+    int x, y, tl, it;
+    const bool ok = pixel_of(cam, i, x, y, tl, it);
+    if (mode == OUT_ROWMAJOR) {
+      if (!ok) return;
+      o = ((size_t)y * cam.width + x) * 3;
+    } else {
+      o = ((size_t)tl * TILE_PIX + it) * 3;  // padding pixels are written as black
+    }
+  }
+  out[o] = (float)c.x, out[o + 1] = (float)c.y, out[o + 2] = (float)c.z;
+}
+
+// rank buffers (tile-major) -> row-major canvas, after the gather on rank 0
+__global__ void __launch_bounds__(256) k_untile(const float* gathered, float* out, int width, int height, int tiles_x, int n_tiles, int n_ranks, long long tiles_per_rank) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)width * height;
+  if (i >= total) return;
+  const int x = (int)(i % width), y = (int)(i / width);
+  const long long tile = (long long)(y / TILE) * tiles_x + (x / TILE);
+  const long long rank = tile % n_ranks, tl = tile / n_ranks;
+  const long long src = ((rank * tiles_per_rank + tl) * TILE_PIX + (long long)(y % TILE) * TILE + (x % TILE)) * 3;
+  out[i * 3] = gathered[src], out[i * 3 + 1] = gathered[src + 1], out[i * 3 + 2] = gathered[src + 2];
+}
+
+// World::is_shadowed for arbitrary points (parity probe)
+template <class R>
+__global__ void __launch_bounds__(256) k_shadow_points(DevScene<R> sc, const float* pts, uint32_t n, uint8_t* out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Work wk;
+  const V3<R> p = {R(pts[3 * i]), R(pts[3 * i + 1]), R(pts[3 * i + 2])};
+  const V3<R> lv = ld3(sc.light_pos) - p;
+  const R distance = sqrt(dot(lv, lv));
+  const V3<R> ldir = {lv.x / distance, lv.y / distance, lv.z / distance};
+  AnyVis<R, false> av(sc, p, ldir, distance + eps<R>(), wk);
+  traverse<R, false>(sc, p, ldir, av, wk);
+  out[i] = av.found ? 1 : 0;
+}
+
+// caller-supplied rays (n*6 floats) -> pool generation 0
+template <class R>
+__global__ void __launch_bounds__(256) k_load_rays(const float* rays, RayPool<R> pool, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  st3(pool.org + 3ull * i, mk<R>(R(rays[6 * i]), R(rays[6 * i + 1]), R(rays[6 * i + 2])));
+  st3(pool.dir + 3ull * i, mk<R>(R(rays[6 * i + 3]), R(rays[6 * i + 4]), R(rays[6 * i + 5])));
+}
+
+// nearest-hit probe output: t as double, prim -> shape index
+template <class R>
+__global__ void __launch_bounds__(256) k_export_hits(DevScene<R> sc, RayPool<R> pool, uint32_t n, double* t_out, int32_t* idx_out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int p = pool.hit_prim[i];
+  if (p < 0) {
+    t_out[i] = (double)NAN;
+    idx_out[i] = -1;
+  } else {
+    t_out[i] = (double)pool.hit_t[i];
+    idx_out[i] = sc.prim_info[p].shape;
+  }
+}
+
+// Color::to_u8 (src/color.rs:97-111): round half away from zero, clamp, NaN -> 0.
+__global__ void __launch_bounds__(256) k_to_u8(const float* in, size_t n, uint8_t* out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = roundf(in[i] * 255.0f);
+  uint8_t b;
+  if (v < 0.0f) b = 0;
+  else if (v > 255.0f) b = 255;
+  else if (v != v) b = 0;
+  else b = (uint8_t)v;
+  out[i] = b;
+}
+
+}  // namespace rt355

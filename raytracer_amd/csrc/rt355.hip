@@ -1,0 +1,624 @@
+// rt355.hip -- implementation of the C ABI declared in include/rt355.h.
+//
+// One context = one GPU + one HIP stream + the per-frame ray pool.  A frame is a fixed sequence of
+// kernel launches on that stream with no host round trip in between: generation sizes live in a
+// device-side control block that the kernels read (grid-stride loops over device-side counts), and the
+// block is read back once, after the frame, for the statistics.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace rt355;
+
+namespace {
+
+thread_local std::string g_err;
+
+int set_err(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return set_err(RT355_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));               \
+  } while (0)
+
+// FLOP weights per unit of work: 1 per add/sub/mul/div/sqrt/min/max/compare, FMA = 2.
+const double F_PRIMARY = 40, F_BOX = 24, F_XFORM = 33;
+const double F_KIND[8] = {28 /*sphere*/, 4 /*plane*/, 20 /*cube*/, 50 /*cylinder*/, 62 /*cone*/, 0, 52 /*triangle*/, 52 /*smooth*/};
+const double F_SHADE = 190, F_REFLECT = 30, F_REFRACT = 35, F_SCHLICK = 25;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes) return RT355_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr, bytes = 0;
+    size_t want = need + need / 8;
+    if (hipMalloc(&p, want) != hipSuccess) {
+      p = nullptr;
+      return set_err(RT355_ENOMEM, "hipMalloc of " + std::to_string(want) + " bytes failed");
+    }
+    bytes = want;
+    return RT355_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr, bytes = 0;
+  }
+};
+
+}  // namespace
+
+struct rt355_ctx {
+  int device = 0;
+  int real_bits = 64;
+  hipStream_t stream = nullptr;
+  double pool_factor = 8.0;
+  bool counting = false, timing = false;
+  int exact_cones = 0;
+  DevBuf org, dir, hit_t, hit_uv, hit_prim, color, mix, child, hitlist, ctl, io_in, io_out, io_out2;
+  hipEvent_t ev[RT355_MAX_LAUNCH + 1];
+  bool ev_ok = false;
+  int n_cu = 256;
+};
+
+struct rt355_scene {
+  rt355_ctx* ctx = nullptr;
+  int real_bits = 64;
+  DevBuf nodes, prim_info, xform, tri, trin, materials;
+  int32_t n_nodes = 0, n_bounded = 0, n_prims = 0, n_materials = 0, max_depth = 0;
+  bool any_secondary = false;
+  float light_pos[3], light_int[3];
+  size_t device_bytes = 0;
+};
+
+namespace {
+
+template <class R>
+DevScene<R> dev_scene(const rt355_scene* s) {
+  DevScene<R> d;
+  d.nodes = (const BvhNode<R>*)s->nodes.p;
+  d.prim_info = (const PrimInfo*)s->prim_info.p;
+  d.xform = (const DevXform<R>*)s->xform.p;
+  d.tri = (const DevTri<R>*)s->tri.p;
+  d.trin = (const DevTriNormals<R>*)s->trin.p;
+  d.materials = (const DevMaterial<R>*)s->materials.p;
+  d.n_nodes = s->n_nodes, d.n_bounded = s->n_bounded, d.n_prims = s->n_prims, d.n_materials = s->n_materials;
+  for (int k = 0; k < 3; ++k) d.light_pos[k] = R(s->light_pos[k]), d.light_int[k] = R(s->light_int[k]);
+  return d;
+}
+
+// Camera::new (src/camera.rs:23-51) in R, plus the inverse of the camera transformation that
+// ray_for_pixel recomputes per pixel (src/camera.rs:67).
+template <class R>
+int dev_camera(const rt355_camera_desc* c, int rank, int n_ranks, DevCamera<R>& out) {
+  if (!(c->hsize >= 1.f) || !(c->vsize >= 1.f) || !std::isfinite(c->hsize) || !std::isfinite(c->vsize) || !std::isfinite(c->fov))
+    return set_err(RT355_EINVAL, "camera: bad size or field of view");
+  const float* m = c->transform;
+  for (int k = 0; k < 16; ++k)
+    if (!std::isfinite(m[k])) return set_err(RT355_EINVAL, "camera: non-finite transformation");
+  if (m[3] != 0.f || m[7] != 0.f || m[11] != 0.f || m[15] != 1.f) return set_err(RT355_EINVAL, "camera: transformation is not affine");
+  auto at = [&](int r, int cc) { return (double)m[cc * 4 + r]; };
+  double a = at(0, 0), b = at(0, 1), cc = at(0, 2), d = at(1, 0), e = at(1, 1), f = at(1, 2), g = at(2, 0), h = at(2, 1), i = at(2, 2);
+  double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  double det = a * A + b * B + cc * C;
+  if (det == 0.0 || !std::isfinite(det)) return set_err(RT355_EINVAL, "camera: singular transformation");
+  double id = 1.0 / det;
+  double r[9] = {A * id, -(b * i - cc * h) * id, (b * f - cc * e) * id, B * id, (a * i - cc * g) * id, -(a * f - cc * d) * id,
+                 C * id, -(a * h - b * g) * id, (a * e - b * d) * id};
+  double tx = at(0, 3), ty = at(1, 3), tz = at(2, 3);
+  for (int row = 0; row < 3; ++row) {
+    out.inv[row * 4 + 0] = R(r[row * 3 + 0]);
+    out.inv[row * 4 + 1] = R(r[row * 3 + 1]);
+    out.inv[row * 4 + 2] = R(r[row * 3 + 2]);
+    out.inv[row * 4 + 3] = R(-(r[row * 3 + 0] * tx + r[row * 3 + 1] * ty + r[row * 3 + 2] * tz));
+  }
+  const R hsize = R(c->hsize), vsize = R(c->vsize), fov = R(c->fov);
+  const R half_view = std::tan(fov / R(2));
+  const R aspect = hsize / vsize;
+  out.half_width = aspect >= R(1) ? half_view : half_view * aspect;
+  out.half_height = aspect >= R(1) ? half_view / aspect : half_view;
+  out.pixel_size = (out.half_width * R(2)) / hsize;
+  out.width = (int)c->hsize, out.height = (int)c->vsize;
+  out.tiles_x = (out.width + TILE - 1) / TILE, out.tiles_y = (out.height + TILE - 1) / TILE;
+  out.n_tiles = out.tiles_x * out.tiles_y;
+  out.rank = rank, out.n_ranks = n_ranks;
+  return RT355_OK;
+}
+
+int64_t tiles_per_rank_of(int width, int height, int n_ranks) {
+  int64_t tx = (width + TILE - 1) / TILE, ty = (height + TILE - 1) / TILE;
+  return (tx * ty + n_ranks - 1) / n_ranks;
+}
+
+template <class R>
+int ensure_pool(rt355_ctx* c, uint64_t n_primary, bool secondary, RayPool<R>& pool) {
+  double factor = secondary ? std::max(1.0, c->pool_factor) : 1.0;
+  uint64_t cap = (uint64_t)std::ceil((double)n_primary * factor) + 64;
+  if (cap >= 0x7fffffffull) return set_err(RT355_EINVAL, "ray pool too large for 32-bit ray ids");
+  int rc;
+  if ((rc = c->org.ensure(cap * 3 * sizeof(R)))) return rc;
+  if ((rc = c->dir.ensure(cap * 3 * sizeof(R)))) return rc;
+  if ((rc = c->hit_t.ensure(cap * sizeof(R)))) return rc;
+  if ((rc = c->hit_uv.ensure(cap * 2 * sizeof(R)))) return rc;
+  if ((rc = c->hit_prim.ensure(cap * sizeof(int32_t)))) return rc;
+  if ((rc = c->color.ensure(cap * 3 * sizeof(R)))) return rc;
+  if ((rc = c->mix.ensure(cap * 3 * sizeof(R)))) return rc;
+  if ((rc = c->child.ensure(cap * 2 * sizeof(int32_t)))) return rc;
+  if ((rc = c->hitlist.ensure(cap * sizeof(int32_t)))) return rc;
+  if ((rc = c->ctl.ensure(sizeof(FrameCtl)))) return rc;
+  pool.org = (R*)c->org.p, pool.dir = (R*)c->dir.p, pool.hit_t = (R*)c->hit_t.p, pool.hit_uv = (R*)c->hit_uv.p;
+  pool.hit_prim = (int32_t*)c->hit_prim.p, pool.color = (R*)c->color.p, pool.mix = (R*)c->mix.p;
+  pool.child = (int32_t*)c->child.p, pool.hitlist = (int32_t*)c->hitlist.p;
+  pool.capacity = (int64_t)cap;
+  return RT355_OK;
+}
+
+struct LaunchLog {
+  int n = 0;
+  int kind[RT355_MAX_LAUNCH], gen[RT355_MAX_LAUNCH];
+};
+
+// The frame: generation 0 rays are already in the pool (ids 0..n_primary).  Leaves the combined
+// generation-0 colours in pool.color[0..n_primary).
+template <class R, bool COUNT>
+int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, uint32_t n_primary, int max_depth, LaunchLog& log) {
+  DevScene<R> sc = dev_scene<R>(s);
+  FrameCtl* ctl = (FrameCtl*)c->ctl.p;
+  FrameCtl init;
+  memset(&init, 0, sizeof(init));
+  init.gen_count[0] = n_primary;
+  HIP_TRY(hipMemcpyAsync(ctl, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+  const int depth = s->any_secondary ? max_depth : 0;  // no reflective / transparent material: one generation
+  const int block = 256;
+  const uint32_t grid0 = (n_primary + block - 1) / block;
+  const uint32_t grid_cap = (uint32_t)c->n_cu * 16;
+  auto rec = [&](int kind, int gen) {
+    if (c->timing && log.n < RT355_MAX_LAUNCH) HIP_TRY(hipEventRecord(c->ev[log.n], c->stream));
+    if (log.n < RT355_MAX_LAUNCH) log.kind[log.n] = kind, log.gen[log.n] = gen;
+    return RT355_OK;
+  };
+  for (int g = 0; g <= depth; ++g) {
+    // generation g > 0 can hold at most twice the hits of g-1; its size is only known on the device
+    const uint32_t grid = g == 0 ? grid0 : std::min<uint32_t>(grid_cap, (uint32_t)((pool.capacity + block - 1) / block));
+    int rc;
+    if ((rc = rec(RT355_K_TRACE, g))) return rc;
+    hipLaunchKernelGGL((k_trace<R, COUNT>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, log.n);
+    log.n++;
+    if ((rc = rec(RT355_K_SHADE, g))) return rc;
+    hipLaunchKernelGGL((k_shade<R, COUNT>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n);
+    log.n++;
+  }
+  for (int g = depth - 1; g >= 0; --g) {
+    const uint32_t grid = g == 0 ? grid0 : std::min<uint32_t>(grid_cap, (uint32_t)((pool.capacity + block - 1) / block));
+    int rc;
+    if ((rc = rec(RT355_K_COMBINE, g))) return rc;
+    hipLaunchKernelGGL((k_combine<R>), dim3(grid), dim3(block), 0, c->stream, pool, ctl, g);
+    log.n++;
+  }
+  if (c->timing && log.n <= RT355_MAX_LAUNCH) HIP_TRY(hipEventRecord(c->ev[log.n], c->stream));
+  HIP_TRY(hipGetLastError());
+  return RT355_OK;
+}
+
+int finish_stats(rt355_ctx* c, const LaunchLog& log, double frame_ms, rt355_stats* st, bool* overflow) {
+  FrameCtl h;
+  HIP_TRY(hipMemcpyAsync(&h, c->ctl.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *overflow = h.overflow != 0;
+  if (!st) return RT355_OK;
+  memset(st, 0, sizeof(*st));
+  for (int g = 0; g < RT355_MAX_GEN; ++g) {
+    st->radiance_rays[g] = h.gen_count[g];
+    st->hits[g] = h.hit_count[g];
+    st->total_radiance += h.gen_count[g];
+    st->total_shadow += h.hit_count[g];
+  }
+  st->frame_ms = frame_ms;
+  st->n_launch = log.n;
+  for (int i = 0; i < log.n && i < RT355_MAX_LAUNCH; ++i) {
+    st->launch_kind[i] = log.kind[i], st->launch_gen[i] = log.gen[i];
+    if (c->timing) {
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+      st->launch_ms[i] = ms;
+    }
+    if (c->counting) {
+      const unsigned long long* w = h.work[i];
+      st->launch_box_tests[i] = w[0];
+      uint64_t prims = 0;
+      double fl = F_BOX * (double)w[0] + F_XFORM * (double)w[1];
+      for (int k = 0; k < 8; ++k) prims += w[2 + k], fl += F_KIND[k] * (double)w[2 + k];
+      st->launch_prim_tests[i] = prims;
+      const int g = log.gen[i];
+      if (log.kind[i] == RT355_K_SHADE) {
+        fl += F_SHADE * (double)h.hit_count[g];
+        // spawned children of this generation: every ray of generation g+1 (reflect or refract)
+        fl += 0.5 * (F_REFLECT + F_REFRACT) * (double)h.gen_count[g + 1];
+      }
+      st->launch_flops[i] = fl;
+    }
+  }
+  return RT355_OK;
+}
+
+template <class R>
+int render_impl(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam, int max_depth, int rank, int n_ranks,
+                int out_mode, float* out_dev, rt355_stats* st) {
+  DevCamera<R> dc;
+  int rc = dev_camera<R>(cam, rank, n_ranks, dc);
+  if (rc) return rc;
+  const int64_t tpr = tiles_per_rank_of(dc.width, dc.height, n_ranks);
+  const uint64_t n_primary = (uint64_t)tpr * TILE_PIX;
+  RayPool<R> pool;
+  if ((rc = ensure_pool<R>(c, n_primary, s->any_secondary && max_depth > 0, pool))) return rc;
+  auto t0 = std::chrono::steady_clock::now();
+  const int block = 256;
+  const uint32_t grid0 = (uint32_t)((n_primary + block - 1) / block);
+  hipLaunchKernelGGL((k_gen_primary<R>), dim3(grid0), dim3(block), 0, c->stream, dc, pool, (uint32_t)n_primary);
+  LaunchLog log;
+  if (c->counting)
+    rc = run_generations<R, true>(c, s, pool, (uint32_t)n_primary, max_depth, log);
+  else
+    rc = run_generations<R, false>(c, s, pool, (uint32_t)n_primary, max_depth, log);
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_write_canvas<R>), dim3(grid0), dim3(block), 0, c->stream, pool, dc, (uint32_t)n_primary, out_mode, out_dev);
+  HIP_TRY(hipGetLastError());
+  bool overflow = false;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if ((rc = finish_stats(c, log, ms, st, &overflow))) return rc;
+  if (st && c->counting && st->n_launch > 0) {
+    // primary-ray generation is charged to the first trace launch; padding pixels are not counted
+    st->launch_flops[0] += F_PRIMARY * (double)dc.width * dc.height / n_ranks;
+  }
+  if (overflow) return set_err(RT355_ECAPACITY, "secondary-ray pool exhausted: raise rt355_ctx_set_pool");
+  return RT355_OK;
+}
+
+template <class R>
+int rays_impl(rt355_ctx* c, const rt355_scene* s, const float* rays_host, size_t n, int max_depth, bool trace_only,
+              float* rgb_out, double* t_out, int32_t* idx_out, rt355_stats* st) {
+  if (n == 0) return RT355_OK;
+  RayPool<R> pool;
+  int rc;
+  if ((rc = ensure_pool<R>(c, n, !trace_only && s->any_secondary && max_depth > 0, pool))) return rc;
+  if ((rc = c->io_in.ensure(n * 6 * sizeof(float)))) return rc;
+  HIP_TRY(hipMemcpyAsync(c->io_in.p, rays_host, n * 6 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  const int block = 256;
+  const uint32_t grid0 = (uint32_t)((n + block - 1) / block);
+  hipLaunchKernelGGL((k_load_rays<R>), dim3(grid0), dim3(block), 0, c->stream, (const float*)c->io_in.p, pool, (uint32_t)n);
+  LaunchLog log;
+  bool overflow = false;
+  if (trace_only) {
+    DevScene<R> sc = dev_scene<R>(s);
+    FrameCtl init;
+    memset(&init, 0, sizeof(init));
+    init.gen_count[0] = (uint32_t)n;
+    HIP_TRY(hipMemcpyAsync(c->ctl.p, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL((k_trace<R, false>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (FrameCtl*)c->ctl.p, 0, 0);
+    if ((rc = c->io_out.ensure(n * sizeof(double)))) return rc;
+    if ((rc = c->io_out2.ensure(n * sizeof(int32_t)))) return rc;
+    hipLaunchKernelGGL((k_export_hits<R>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (uint32_t)n, (double*)c->io_out.p, (int32_t*)c->io_out2.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(t_out, c->io_out.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(idx_out, c->io_out2.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT355_OK;
+  }
+  auto t0 = std::chrono::steady_clock::now();
+  if (c->counting)
+    rc = run_generations<R, true>(c, s, pool, (uint32_t)n, max_depth, log);
+  else
+    rc = run_generations<R, false>(c, s, pool, (uint32_t)n, max_depth, log);
+  if (rc) return rc;
+  if ((rc = c->io_out.ensure(n * 3 * sizeof(float)))) return rc;
+  DevCamera<R> dummy;
+  memset(&dummy, 0, sizeof(dummy));
+  hipLaunchKernelGGL((k_write_canvas<R>), dim3(grid0), dim3(block), 0, c->stream, pool, dummy, (uint32_t)n, (int)OUT_LINEAR, (float*)c->io_out.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(rgb_out, c->io_out.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if ((rc = finish_stats(c, log, ms, st, &overflow))) return rc;
+  if (overflow) return set_err(RT355_ECAPACITY, "secondary-ray pool exhausted: raise rt355_ctx_set_pool");
+  return RT355_OK;
+}
+
+template <class R>
+int upload_impl(rt355_ctx* c, const HostScene& hs, rt355_scene* s) {
+  const size_t np = hs.prims.size(), nn = hs.nodes.size(), nm = hs.materials.size();
+  std::vector<BvhNode<R>> nodes(nn);
+  for (size_t i = 0; i < nn; ++i) {
+    for (int k = 0; k < 3; ++k) {
+      // boxes were padded in double; when narrowing to float round outward
+      auto down = [](double v) { R r = (R)v; if ((double)r > v) r = std::nextafter(r, -std::numeric_limits<R>::infinity()); return r; };
+      auto up = [](double v) { R r = (R)v; if ((double)r < v) r = std::nextafter(r, std::numeric_limits<R>::infinity()); return r; };
+      nodes[i].lo0[k] = down(hs.nodes[i].lo0[k]), nodes[i].hi0[k] = up(hs.nodes[i].hi0[k]);
+      nodes[i].lo1[k] = down(hs.nodes[i].lo1[k]), nodes[i].hi1[k] = up(hs.nodes[i].hi1[k]);
+    }
+    nodes[i].c0 = hs.nodes[i].c0, nodes[i].c1 = hs.nodes[i].c1, nodes[i].pad0 = nodes[i].pad1 = 0;
+  }
+  std::vector<PrimInfo> info(np);
+  std::vector<DevXform<R>> xf(np);
+  bool any_tri = false;
+  for (size_t i = 0; i < np; ++i) {
+    const HostPrim& p = hs.prims[i];
+    info[i].shape = p.shape;
+    info[i].flags = p.flags | (p.material << PF_MAT_SHIFT);
+    for (int k = 0; k < 12; ++k) xf[i].r[k] = (R)p.inv[k];
+    xf[i].ymin = (R)p.ymin, xf[i].ymax = (R)p.ymax, xf[i].pad0 = xf[i].pad1 = 0;
+    if ((p.flags & PF_KIND_MASK) >= RT355_TRIANGLE) any_tri = true;
+  }
+  std::vector<DevTri<R>> tri(any_tri ? np : 0);
+  std::vector<DevTriNormals<R>> trin(any_tri ? np : 0);
+  if (any_tri)
+    for (size_t i = 0; i < np; ++i) {
+      const HostPrim& p = hs.prims[i];
+      for (int k = 0; k < 3; ++k) {
+        tri[i].p1[k] = (R)p.p1[k], tri[i].e1[k] = (R)p.e1[k], tri[i].e2[k] = (R)p.e2[k], tri[i].pad[k] = 0;
+        trin[i].n1[k] = (R)p.n1[k], trin[i].n2[k] = (R)p.n2[k], trin[i].n3[k] = (R)p.n3[k], trin[i].nf[k] = (R)p.nf[k];
+      }
+    }
+  std::vector<DevMaterial<R>> mats(nm);
+  for (size_t i = 0; i < nm; ++i) {
+    const rt355_material& m = hs.materials[i];
+    for (int k = 0; k < 3; ++k) mats[i].color[k] = (R)m.color[k], mats[i].c1[k] = (R)m.c1[k], mats[i].c2[k] = (R)m.c2[k];
+    mats[i].ambient = (R)m.ambient, mats[i].diffuse = (R)m.diffuse, mats[i].specular = (R)m.specular;
+    mats[i].shininess = (R)m.shininess, mats[i].reflective = (R)m.reflective, mats[i].refractive = (R)m.refractive;
+    mats[i].transparency = (R)m.transparency, mats[i].pattern_kind = m.pattern_kind, mats[i].pad = 0;
+  }
+  auto put = [&](DevBuf& b, const void* src, size_t bytes) -> int {
+    int rc = b.ensure(std::max<size_t>(bytes, 16));
+    if (rc) return rc;
+    if (bytes) HIP_TRY(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    s->device_bytes += bytes;
+    return RT355_OK;
+  };
+  int rc;
+  if ((rc = put(s->nodes, nodes.data(), nn * sizeof(BvhNode<R>)))) return rc;
+  if ((rc = put(s->prim_info, info.data(), np * sizeof(PrimInfo)))) return rc;
+  if ((rc = put(s->xform, xf.data(), np * sizeof(DevXform<R>)))) return rc;
+  if ((rc = put(s->tri, tri.data(), tri.size() * sizeof(DevTri<R>)))) return rc;
+  if ((rc = put(s->trin, trin.data(), trin.size() * sizeof(DevTriNormals<R>)))) return rc;
+  if ((rc = put(s->materials, mats.data(), nm * sizeof(DevMaterial<R>)))) return rc;
+  s->n_nodes = (int32_t)nn, s->n_bounded = hs.n_bounded, s->n_prims = (int32_t)np, s->n_materials = (int32_t)nm;
+  s->max_depth = hs.max_depth, s->any_secondary = hs.any_secondary;
+  return RT355_OK;
+}
+
+int check_ctx(rt355_ctx* c) {
+  if (!c) return set_err(RT355_EINVAL, "null context");
+  HIP_TRY(hipSetDevice(c->device));
+  return RT355_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt355_last_error(void) { return g_err.c_str(); }
+int rt355_version(void) { return RT355_VERSION; }
+
+int rt355_ctx_create(rt355_ctx** out, int device_id, int real_bits) {
+  if (!out) return set_err(RT355_EINVAL, "null out pointer");
+  *out = nullptr;
+  if (real_bits != 32 && real_bits != 64) return set_err(RT355_EINVAL, "real_bits must be 32 or 64");
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  if (device_id < 0 || device_id >= n) return set_err(RT355_EINVAL, "no such device");
+  HIP_TRY(hipSetDevice(device_id));
+  rt355_ctx* c = new rt355_ctx();
+  c->device = device_id, c->real_bits = real_bits;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return set_err(RT355_EHIP, "hipStreamCreate failed");
+  }
+  for (int i = 0; i <= RT355_MAX_LAUNCH; ++i)
+    if (hipEventCreate(&c->ev[i]) != hipSuccess) {
+      delete c;
+      return set_err(RT355_EHIP, "hipEventCreate failed");
+    }
+  c->ev_ok = true;
+  *out = c;
+  return RT355_OK;
+}
+
+void rt355_ctx_destroy(rt355_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (DevBuf* b : {&c->org, &c->dir, &c->hit_t, &c->hit_uv, &c->hit_prim, &c->color, &c->mix, &c->child, &c->hitlist, &c->ctl, &c->io_in, &c->io_out, &c->io_out2}) b->release();
+  if (c->ev_ok)
+    for (int i = 0; i <= RT355_MAX_LAUNCH; ++i) (void)hipEventDestroy(c->ev[i]);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int rt355_ctx_set_pool(rt355_ctx* c, double rays_per_pixel) {
+  if (!c || !(rays_per_pixel >= 1.0) || rays_per_pixel > 128.0) return set_err(RT355_EINVAL, "pool factor must be in [1,128]");
+  c->pool_factor = rays_per_pixel;
+  return RT355_OK;
+}
+int rt355_ctx_set_exact_cones(rt355_ctx* c, int mode) {
+  if (!c || (mode != 0 && mode != 1)) return set_err(RT355_EINVAL, "mode must be 0 or 1");
+  c->exact_cones = mode;
+  return RT355_OK;
+}
+int rt355_ctx_set_counting(rt355_ctx* c, int on) {
+  if (!c) return set_err(RT355_EINVAL, "null context");
+  c->counting = on != 0;
+  return RT355_OK;
+}
+int rt355_ctx_set_timing(rt355_ctx* c, int on) {
+  if (!c) return set_err(RT355_EINVAL, "null context");
+  c->timing = on != 0;
+  return RT355_OK;
+}
+
+int rt355_scene_upload(rt355_ctx* c, const rt355_shape_desc* shapes, size_t n_shapes, const rt355_light_desc* light, rt355_scene** out) {
+  if (!out) return set_err(RT355_EINVAL, "null out pointer");
+  *out = nullptr;
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!shapes && n_shapes) return set_err(RT355_EINVAL, "null shapes");
+  if (!light) return set_err(RT355_EINVAL, "null light");
+  for (int k = 0; k < 3; ++k)
+    if (std::isnan(light->position[k]) || std::isnan(light->intensity[k])) return set_err(RT355_EINVAL, "NaN in light");
+  HostScene hs;
+  char err[256] = {0};
+  // outward padding of every BVH box, relative to its magnitude: a few hundred ulps of the kernel's type
+  const double pad_rel = c->real_bits == 32 ? 256.0 * 1.1920929e-7 : 1e-9;
+  rc = build_host_scene(shapes, n_shapes, pad_rel, c->exact_cones ? INT64_MAX : 32, hs, err, sizeof(err));
+  if (rc) return set_err(rc, err);
+  rt355_scene* s = new rt355_scene();
+  s->ctx = c, s->real_bits = c->real_bits;
+  for (int k = 0; k < 3; ++k) s->light_pos[k] = light->position[k], s->light_int[k] = light->intensity[k];
+  rc = c->real_bits == 32 ? upload_impl<float>(c, hs, s) : upload_impl<double>(c, hs, s);
+  if (rc) {
+    rt355_scene_destroy(s);
+    return rc;
+  }
+  *out = s;
+  return RT355_OK;
+}
+
+void rt355_scene_destroy(rt355_scene* s) {
+  if (!s) return;
+  if (s->ctx) (void)hipSetDevice(s->ctx->device);
+  for (DevBuf* b : {&s->nodes, &s->prim_info, &s->xform, &s->tri, &s->trin, &s->materials}) b->release();
+  delete s;
+}
+
+int rt355_scene_info(const rt355_scene* s, uint64_t out[5]) {
+  if (!s || !out) return set_err(RT355_EINVAL, "null argument");
+  out[0] = s->n_nodes, out[1] = s->n_bounded, out[2] = s->n_prims - s->n_bounded, out[3] = s->max_depth, out[4] = s->device_bytes;
+  return RT355_OK;
+}
+
+int64_t rt355_tiles_per_rank(const rt355_camera_desc* cam, int n_ranks) {
+  if (!cam || n_ranks < 1) return -1;
+  return tiles_per_rank_of((int)cam->hsize, (int)cam->vsize, n_ranks);
+}
+
+static int check_render_args(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam, int max_depth) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!s || !cam) return set_err(RT355_EINVAL, "null argument");
+  if (s->ctx != c) return set_err(RT355_EINVAL, "scene belongs to another context");
+  if (max_depth < 0 || max_depth >= RT355_MAX_GEN) return set_err(RT355_EINVAL, "max_depth must be in [0,7]");
+  return RT355_OK;
+}
+
+int rt355_render(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam, int max_depth, float* rgb_out, rt355_stats* stats) {
+  int rc = check_render_args(c, s, cam, max_depth);
+  if (rc) return rc;
+  if (!rgb_out) return set_err(RT355_EINVAL, "null output");
+  const size_t n = (size_t)(int)cam->hsize * (size_t)(int)cam->vsize * 3;
+  if ((rc = c->io_out.ensure(n * sizeof(float)))) return rc;
+  rc = c->real_bits == 32 ? render_impl<float>(c, s, cam, max_depth, 0, 1, OUT_ROWMAJOR, (float*)c->io_out.p, stats)
+                          : render_impl<double>(c, s, cam, max_depth, 0, 1, OUT_ROWMAJOR, (float*)c->io_out.p, stats);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(rgb_out, c->io_out.p, n * sizeof(float), hipMemcpyDeviceToHost));
+  return RT355_OK;
+}
+
+int rt355_render_tiles(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam, int max_depth, int rank, int n_ranks,
+                       float* tiles_out_dev, rt355_stats* stats) {
+  int rc = check_render_args(c, s, cam, max_depth);
+  if (rc) return rc;
+  if (!tiles_out_dev) return set_err(RT355_EINVAL, "null output");
+  if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return set_err(RT355_EINVAL, "bad rank / n_ranks");
+  return c->real_bits == 32 ? render_impl<float>(c, s, cam, max_depth, rank, n_ranks, OUT_TILES, tiles_out_dev, stats)
+                            : render_impl<double>(c, s, cam, max_depth, rank, n_ranks, OUT_TILES, tiles_out_dev, stats);
+}
+
+int rt355_untile(rt355_ctx* c, const rt355_camera_desc* cam, int n_ranks, const float* gathered_dev, float* rgb_out_dev) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!cam || !gathered_dev || !rgb_out_dev || n_ranks < 1) return set_err(RT355_EINVAL, "bad argument");
+  const int w = (int)cam->hsize, h = (int)cam->vsize;
+  if (w < 1 || h < 1) return set_err(RT355_EINVAL, "bad canvas size");
+  const int tiles_x = (w + TILE - 1) / TILE, tiles_y = (h + TILE - 1) / TILE;
+  const long long total = (long long)w * h;
+  hipLaunchKernelGGL(k_untile, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, gathered_dev, rgb_out_dev, w, h, tiles_x,
+                     tiles_x * tiles_y, n_ranks, (long long)tiles_per_rank_of(w, h, n_ranks));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RT355_OK;
+}
+
+int rt355_color_at(rt355_ctx* c, const rt355_scene* s, const float* rays, size_t n, int max_depth, float* rgb_out, rt355_stats* stats) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!s || (!rays && n) || (!rgb_out && n)) return set_err(RT355_EINVAL, "null argument");
+  if (s->ctx != c) return set_err(RT355_EINVAL, "scene belongs to another context");
+  if (max_depth < 0 || max_depth >= RT355_MAX_GEN) return set_err(RT355_EINVAL, "max_depth must be in [0,7]");
+  return c->real_bits == 32 ? rays_impl<float>(c, s, rays, n, max_depth, false, rgb_out, nullptr, nullptr, stats)
+                            : rays_impl<double>(c, s, rays, n, max_depth, false, rgb_out, nullptr, nullptr, stats);
+}
+
+int rt355_trace_sample(rt355_ctx* c, const rt355_scene* s, const float* rays, size_t n, double* t_out, int32_t* shape_index_out) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!s || (!rays && n) || ((!t_out || !shape_index_out) && n)) return set_err(RT355_EINVAL, "null argument");
+  if (s->ctx != c) return set_err(RT355_EINVAL, "scene belongs to another context");
+  return c->real_bits == 32 ? rays_impl<float>(c, s, rays, n, 0, true, nullptr, t_out, shape_index_out, nullptr)
+                            : rays_impl<double>(c, s, rays, n, 0, true, nullptr, t_out, shape_index_out, nullptr);
+}
+
+int rt355_is_shadowed(rt355_ctx* c, const rt355_scene* s, const float* points, size_t n, uint8_t* out) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!s || (!points && n) || (!out && n)) return set_err(RT355_EINVAL, "null argument");
+  if (s->ctx != c) return set_err(RT355_EINVAL, "scene belongs to another context");
+  if (n == 0) return RT355_OK;
+  if ((rc = c->io_in.ensure(n * 3 * sizeof(float)))) return rc;
+  if ((rc = c->io_out.ensure(n))) return rc;
+  HIP_TRY(hipMemcpyAsync(c->io_in.p, points, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  if (c->real_bits == 32)
+    hipLaunchKernelGGL((k_shadow_points<float>), dim3(grid), dim3(256), 0, c->stream, dev_scene<float>(s), (const float*)c->io_in.p, (uint32_t)n, (uint8_t*)c->io_out.p);
+  else
+    hipLaunchKernelGGL((k_shadow_points<double>), dim3(grid), dim3(256), 0, c->stream, dev_scene<double>(s), (const float*)c->io_in.p, (uint32_t)n, (uint8_t*)c->io_out.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, c->io_out.p, n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RT355_OK;
+}
+
+int rt355_to_u8(rt355_ctx* c, const float* rgb, size_t n, uint8_t* out) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if ((!rgb || !out) && n) return set_err(RT355_EINVAL, "null argument");
+  if (n == 0) return RT355_OK;
+  if ((rc = c->io_in.ensure(n * sizeof(float)))) return rc;
+  if ((rc = c->io_out.ensure(n))) return rc;
+  HIP_TRY(hipMemcpyAsync(c->io_in.p, rgb, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_to_u8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float*)c->io_in.p, n, (uint8_t*)c->io_out.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, c->io_out.p, n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RT355_OK;
+}
+
+void rt355_flop_table(double out[16]) {
+  out[0] = F_PRIMARY, out[1] = F_BOX, out[2] = F_XFORM;
+  for (int k = 0; k < 8; ++k) out[3 + k] = F_KIND[k];
+  out[11] = F_SHADE, out[12] = F_REFLECT, out[13] = F_REFRACT, out[14] = F_SCHLICK, out[15] = 0;
+}
+}

@@ -1,0 +1,146 @@
+// rt355_device.h -- data layout shared by the host scene builder, the C ABI and the HIP kernels.
+//
+// Everything the kernels read is laid out here once, at scene upload:
+//   * prims: every non-Group shape, BVH leaf order first (bounded shapes), then the shapes that have no
+//     finite bound (planes, uncapped cylinders / cones).  A "prim id" p indexes all per-prim arrays.
+//   * nodes: binary BVH, each node carries BOTH child boxes so one fetch decides both descents.
+//   * materials: deduplicated table (material.rs:6-17 + pattern.rs colours).
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/rt355.h"
+
+namespace rt355 {
+
+constexpr int TILE = 32;             // image tile edge; tile t belongs to rank t % n_ranks
+constexpr int TILE_PIX = TILE * TILE;
+constexpr int STACK_DEPTH = 64;      // traversal stack entries; the builder keeps the tree shallower
+constexpr int MAX_TREE_DEPTH = 60;
+constexpr int LEAF_MAX = 4;
+constexpr int N_WORK_COUNTERS = 12;  // per launch: [0] box tests, [1] xforms, [2..10) prim tests per kind
+
+// prim_info.y bits
+constexpr int PF_KIND_MASK = 7;
+constexpr int PF_CLOSED = 8;
+constexpr int PF_IDENTITY = 16;  // transformation is exactly the identity: the ray is used as is
+constexpr int PF_MAT_SHIFT = 8;
+
+struct PrimInfo {
+  int32_t shape;  // index in World.shapes
+  int32_t flags;  // kind | PF_* | material << PF_MAT_SHIFT
+};
+
+template <class R>
+struct BvhNode {
+  R lo0[3], hi0[3], lo1[3], hi1[3];
+  int32_t c0, c1;  // >= 0: inner node index; < 0: leaf, ~c = first | (count << 26)
+  int32_t pad0, pad1;
+};
+
+template <class R>
+struct DevMaterial {
+  R color[3];
+  R ambient, diffuse, specular, shininess, reflective, refractive, transparency;
+  R c1[3], c2[3];
+  int32_t pattern_kind;
+  int32_t pad;
+};
+
+template <class R>
+struct DevXform {  // rows 0..2 of the inverse transformation (affine): x' = r0 . (x,y,z,w)
+  R r[12];
+  R ymin, ymax;  // cylinder / cone extents
+  R pad0, pad1;
+};
+
+template <class R>
+struct DevTri {  // Moeller-Trumbore operands, object space (src/triangle.rs:83-84)
+  R p1[3], e1[3], e2[3];
+  R pad[3];
+};
+
+template <class R>
+struct DevTriNormals {  // smooth triangle: n1,n2,n3; flat triangle: nf (src/triangle.rs:85)
+  R n1[3], n2[3], n3[3], nf[3];
+};
+
+template <class R>
+struct DevScene {
+  const BvhNode<R>* nodes;        // n_nodes (0 when there is no bounded prim)
+  const PrimInfo* prim_info;      // n_prims
+  const DevXform<R>* xform;       // n_prims
+  const DevTri<R>* tri;           // n_prims (valid for triangle kinds)
+  const DevTriNormals<R>* trin;   // n_prims (valid for triangle kinds)
+  const DevMaterial<R>* materials;
+  int32_t n_nodes, n_bounded, n_prims, n_materials;
+  R light_pos[3], light_int[3];
+};
+
+template <class R>
+struct DevCamera {
+  R inv[12];  // rows 0..2 of the inverse camera transformation
+  R half_width, half_height, pixel_size;
+  int32_t width, height, tiles_x, tiles_y, n_tiles;
+  int32_t rank, n_ranks;
+};
+
+// Per-frame ray pool, structure of arrays indexed by ray id.  Generation g occupies the id range
+// [gen_start[g], gen_start[g] + gen_count[g]); generation 0 is the primary rays.
+template <class R>
+struct RayPool {
+  R* org;      // 3 per ray
+  R* dir;      // 3 per ray
+  R* hit_t;    // nearest t >= 0
+  R* hit_uv;   // 2 per ray (smooth triangles)
+  int32_t* hit_prim;   // prim id, -1 = miss
+  R* color;    // 3 per ray: surface colour, replaced by the combined colour in the combine pass
+  R* mix;      // 3 per ray: reflective, transparency, schlick reflectance (< 0: plain sum)
+  int32_t* child;      // 2 per ray: reflected, refracted child ray id (-1 = none)
+  int32_t* hitlist;    // per generation region: ids of the rays that hit something
+  int64_t capacity;
+};
+
+// Small device-resident control block; read back once per frame.
+struct FrameCtl {
+  uint32_t gen_start[RT355_MAX_GEN + 1];
+  uint32_t gen_count[RT355_MAX_GEN + 1];
+  uint32_t hit_count[RT355_MAX_GEN + 1];
+  uint32_t overflow;
+  uint32_t pad;
+  unsigned long long work[RT355_MAX_LAUNCH][N_WORK_COUNTERS];
+};
+
+// ---- host scene builder output (scene_build.cpp) -------------------------------------------------
+struct HostPrim {
+  int32_t shape;   // index in World.shapes
+  int32_t flags;   // kind | PF_*
+  int32_t material;
+  double inv[12];
+  double ymin, ymax;
+  double p1[3], e1[3], e2[3];
+  double n1[3], n2[3], n3[3], nf[3];
+  double lo[3], hi[3];
+  bool bounded;
+};
+
+struct HostNode {
+  double lo0[3], hi0[3], lo1[3], hi1[3];
+  int32_t c0, c1;
+};
+
+struct HostScene {
+  std::vector<HostPrim> prims;  // final order: BVH leaf order, then the unbounded prims
+  int32_t n_bounded = 0;
+  std::vector<HostNode> nodes;
+  int32_t max_depth = 0;
+  std::vector<rt355_material> materials;
+  bool any_secondary = false;  // some material is reflective or transparent
+};
+
+// Returns 0 or RT355_EINVAL (message in err).  pad_rel: relative outward padding of every box.
+// cone_exact_limit: scenes with at most this many truncated cones keep them in the every-ray list.
+int build_host_scene(const rt355_shape_desc* shapes, size_t n, double pad_rel, int64_t cone_exact_limit, HostScene& out, char* err, size_t errlen);
+
+}  // namespace rt355

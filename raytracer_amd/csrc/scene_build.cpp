@@ -1,0 +1,393 @@
+// scene_build.cpp -- host side of rt355_scene_upload: runs ONCE per scene.
+//
+// What the reference redoes for every shape and every ray is hoisted here:
+//   * Ray::inv_transform inverts the shape's matrix twice per shape per ray (src/ray.rs:32-37) and
+//     Shape::normal a third time per hit (src/shape.rs:111-136): the inverse is computed once, in double,
+//     from the f32 matrix.  Transforms must be affine (every builder in src/matrix.rs:15-89 and
+//     src/tuple.rs:50-60 is); anything else is RT355_EINVAL where the reference would unwrap() a None.
+//   * triangle edges e1 = p2-p1, e2 = p3-p1 and the flat normal normalize((p3-p2) x (p2-p1))
+//     (src/triangle.rs:65-66, 83-85).
+//   * World::intersect is a brute-force loop over all shapes (src/world.rs:35-44); there is no spatial
+//     index in the reference (src/bound.rs is an unused AABB struct and Shape::bound() returns a
+//     placeholder for triangles, src/shape.rs:679-692), so the BVH below is new: binned SAH, binary,
+//     each node storing both child boxes.  Shapes without a finite bound (planes, cylinders / cones with
+//     infinite extents, src/cylinder.rs:40-47) go to a side list that every ray tests.
+//   * Group entries are inert in a World (src/shape.rs:376): dropped from the prim list, their index
+//     stays reserved so that prim -> shape index is the position in World.shapes.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+
+#include "rt355_device.h"
+
+namespace rt355 {
+namespace {
+
+constexpr double EPS_F = 1.0e-3;  // src/epsilon.rs:1
+
+struct Box {
+  double lo[3], hi[3];
+  void reset() {
+    for (int k = 0; k < 3; ++k) lo[k] = INFINITY, hi[k] = -INFINITY;
+  }
+  void grow(const double* p) {
+    for (int k = 0; k < 3; ++k) lo[k] = std::min(lo[k], p[k]), hi[k] = std::max(hi[k], p[k]);
+  }
+  void grow(const Box& b) {
+    for (int k = 0; k < 3; ++k) lo[k] = std::min(lo[k], b.lo[k]), hi[k] = std::max(hi[k], b.hi[k]);
+  }
+  double area() const {
+    double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    if (dx < 0 || dy < 0 || dz < 0) return 0;
+    return 2 * (dx * dy + dy * dz + dz * dx);
+  }
+};
+
+bool affine_inverse(const float* m, double inv[12]) {
+  // m is column-major: element (r,c) = m[c*4+r]
+  auto at = [&](int r, int c) { return (double)m[c * 4 + r]; };
+  if (m[3] != 0.f || m[7] != 0.f || m[11] != 0.f || m[15] != 1.f) return false;
+  double a = at(0, 0), b = at(0, 1), c = at(0, 2), d = at(1, 0), e = at(1, 1), f = at(1, 2), g = at(2, 0), h = at(2, 1), i = at(2, 2);
+  double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  double det = a * A + b * B + c * C;
+  if (det == 0.0 || !std::isfinite(det)) return false;
+  double id = 1.0 / det;
+  double r[9] = {A * id, -(b * i - c * h) * id, (b * f - c * e) * id,
+                 B * id, (a * i - c * g) * id, -(a * f - c * d) * id,
+                 C * id, -(a * h - b * g) * id, (a * e - b * d) * id};
+  double tx = at(0, 3), ty = at(1, 3), tz = at(2, 3);
+  for (int row = 0; row < 3; ++row) {
+    inv[row * 4 + 0] = r[row * 3 + 0];
+    inv[row * 4 + 1] = r[row * 3 + 1];
+    inv[row * 4 + 2] = r[row * 3 + 2];
+    inv[row * 4 + 3] = -(r[row * 3 + 0] * tx + r[row * 3 + 1] * ty + r[row * 3 + 2] * tz);
+  }
+  for (int k = 0; k < 12; ++k)
+    if (!std::isfinite(inv[k])) return false;
+  return true;
+}
+
+void xf_point(const float* m, const double* p, double* out) {
+  for (int r = 0; r < 3; ++r) out[r] = (double)m[0 * 4 + r] * p[0] + (double)m[1 * 4 + r] * p[1] + (double)m[2 * 4 + r] * p[2] + (double)m[3 * 4 + r];
+}
+
+bool is_identity(const float* m) {
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r)
+      if (m[c * 4 + r] != (r == c ? 1.f : 0.f)) return false;
+  return true;
+}
+
+// World-space box of the object-space box [lx,hx]x[ly,hy]x[lz,hz] under m.
+void box_of_local(const float* m, double lx, double hx, double ly, double hy, double lz, double hz, Box& b) {
+  b.reset();
+  for (int k = 0; k < 8; ++k) {
+    double p[3] = {k & 1 ? hx : lx, k & 2 ? hy : ly, k & 4 ? hz : lz}, q[3];
+    xf_point(m, p, q);
+    b.grow(q);
+  }
+}
+
+struct BuildNode {
+  Box box;
+  int left = -1, right = -1;  // children (build nodes)
+  int first = 0, count = 0;   // leaf range in the ordered prim list
+};
+
+struct Builder {
+  std::vector<HostPrim>& prims;  // bounded prims only, reordered in place
+  std::vector<Box> boxes;
+  std::vector<double> cx, cy, cz;
+  std::vector<int> order;
+  std::vector<BuildNode> nodes;
+  int max_depth = 0;
+
+  explicit Builder(std::vector<HostPrim>& p) : prims(p) {}
+
+  double centroid(int i, int axis) const { return axis == 0 ? cx[i] : axis == 1 ? cy[i] : cz[i]; }
+
+  int build(int first, int count, int depth) {
+    max_depth = std::max(max_depth, depth);
+    int id = (int)nodes.size();
+    nodes.emplace_back();
+    Box box, cbox;
+    box.reset(), cbox.reset();
+    for (int k = first; k < first + count; ++k) {
+      int i = order[k];
+      box.grow(boxes[i]);
+      double c[3] = {cx[i], cy[i], cz[i]};
+      cbox.grow(c);
+    }
+    nodes[id].box = box;
+    auto make_leaf = [&]() {
+      nodes[id].first = first, nodes[id].count = count;
+      return id;
+    };
+    if (count <= 1) return make_leaf();
+    bool must_split = count > LEAF_MAX;
+    if (depth >= MAX_TREE_DEPTH - 1 && count <= 31) return make_leaf();  // leaf count field is 5 bits
+
+    constexpr int NB = 16;
+    double best_cost = INFINITY;
+    int best_axis = -1, best_bin = -1;
+    for (int axis = 0; axis < 3; ++axis) {
+      double lo = cbox.lo[axis], hi = cbox.hi[axis];
+      if (!(hi > lo)) continue;
+      double scale = NB / (hi - lo);
+      Box bb[NB];
+      int bc[NB] = {0};
+      for (auto& b : bb) b.reset();
+      for (int k = first; k < first + count; ++k) {
+        int i = order[k];
+        int bin = std::min(NB - 1, std::max(0, (int)((centroid(i, axis) - lo) * scale)));
+        bb[bin].grow(boxes[i]);
+        bc[bin]++;
+      }
+      double la[NB], ra[NB];
+      int lc[NB], rc[NB];
+      Box acc;
+      acc.reset();
+      int n = 0;
+      for (int b = 0; b < NB; ++b) {
+        acc.grow(bb[b]);
+        n += bc[b];
+        la[b] = acc.area(), lc[b] = n;
+      }
+      acc.reset();
+      n = 0;
+      for (int b = NB - 1; b >= 0; --b) {
+        acc.grow(bb[b]);
+        n += bc[b];
+        ra[b] = acc.area(), rc[b] = n;
+      }
+      for (int b = 0; b < NB - 1; ++b) {
+        if (lc[b] == 0 || rc[b + 1] == 0) continue;
+        double cost = la[b] * lc[b] + ra[b + 1] * rc[b + 1];
+        if (cost < best_cost) best_cost = cost, best_axis = axis, best_bin = b;
+      }
+    }
+    int mid = -1;
+    if (best_axis >= 0) {
+      double leaf_cost = box.area() * count;
+      // traversal step ~ 1 prim test in cost
+      if (!must_split && best_cost + box.area() * 1.0 >= leaf_cost) return make_leaf();
+      double lo = cbox.lo[best_axis], hi = cbox.hi[best_axis];
+      double scale = NB / (hi - lo);
+      auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](int i) {
+        int bin = std::min(NB - 1, std::max(0, (int)((centroid(i, best_axis) - lo) * scale)));
+        return bin <= best_bin;
+      });
+      mid = (int)(it - order.begin());
+    }
+    if (mid <= first || mid >= first + count) {
+      // all centroids coincide (or binning failed): split the range in half by index
+      if (!must_split) return make_leaf();
+      mid = first + count / 2;
+    }
+    int l = build(first, mid - first, depth + 1);
+    int r = build(mid, first + count - mid, depth + 1);
+    nodes[id].left = l, nodes[id].right = r;
+    return id;
+  }
+};
+
+int32_t encode_leaf(int first, int count) { return ~(int32_t)((uint32_t)first | ((uint32_t)count << 26)); }
+
+}  // namespace
+
+int build_host_scene(const rt355_shape_desc* shapes, size_t n, double pad_rel, int64_t cone_exact_limit, HostScene& out, char* err, size_t errlen) {
+  // A ray parallel to one half of a truncated cone hits it anywhere on the infinite double cone
+  // (src/shape.rs:295-298 pushes c / (-2b) without the min < y < max test): no finite box holds that.
+  int64_t n_trunc_cones = 0;
+  for (size_t i = 0; i < n; ++i)
+    if (shapes[i].kind == RT355_CONE && std::isfinite(shapes[i].min) && std::isfinite(shapes[i].max)) ++n_trunc_cones;
+  const bool cones_unbounded = n_trunc_cones <= cone_exact_limit;
+  auto fail = [&](const char* what, size_t i) {
+    snprintf(err, errlen, "shape %zu: %s", i, what);
+    return RT355_EINVAL;
+  };
+  std::map<std::string, int> mat_index;
+  std::vector<HostPrim> bounded, unbounded;
+  for (size_t i = 0; i < n; ++i) {
+    const rt355_shape_desc& d = shapes[i];
+    if (d.kind < 0 || d.kind > RT355_SMOOTH_TRIANGLE) return fail("unknown kind", i);
+    if (d.kind == RT355_GROUP) continue;
+    HostPrim p;
+    memset(&p, 0, sizeof(p));
+    p.shape = (int32_t)i;
+    for (int k = 0; k < 16; ++k)
+      if (!std::isfinite(d.m[k])) return fail("non-finite transformation", i);
+    if (!affine_inverse(d.m, p.inv)) return fail("transformation is singular or not affine", i);
+    // material table
+    const float* mf = &d.mat.color[0];
+    for (size_t k = 0; k < sizeof(rt355_material) / 4; ++k) {
+      if (k == 10) continue;  // pattern_kind (int)
+      if (std::isnan(mf[k])) return fail("NaN in material", i);
+    }
+    if (d.mat.pattern_kind < 0 || d.mat.pattern_kind > RT355_PATTERN_TEST) return fail("unknown pattern kind", i);
+    std::string key((const char*)&d.mat, sizeof(rt355_material));
+    auto it = mat_index.find(key);
+    if (it == mat_index.end()) {
+      it = mat_index.emplace(key, (int)out.materials.size()).first;
+      out.materials.push_back(d.mat);
+      if (d.mat.reflective != 0.f || d.mat.transparency != 0.f) out.any_secondary = true;
+    }
+    p.material = it->second;
+    p.flags = d.kind | (d.closed ? PF_CLOSED : 0) | (is_identity(d.m) ? PF_IDENTITY : 0);
+    p.ymin = d.min, p.ymax = d.max;
+    if (std::isnan(d.min) || std::isnan(d.max)) return fail("NaN extent", i);
+    Box b;
+    b.reset();
+    p.bounded = true;
+    switch (d.kind) {
+      case RT355_SPHERE:
+      case RT355_CUBE:
+        box_of_local(d.m, -1, 1, -1, 1, -1, 1, b);
+        break;
+      case RT355_PLANE:
+        p.bounded = false;
+        break;
+      case RT355_CYLINDER: {
+        if (!std::isfinite(d.min) || !std::isfinite(d.max)) {
+          p.bounded = false;
+          break;
+        }
+        // caps accept x^2+z^2 <= 1 + EPSILON (src/shape.rs:468-472)
+        double r = std::sqrt(1.0 + EPS_F) * (1 + 1e-6);
+        box_of_local(d.m, -r, r, std::min(d.min, d.max), std::max(d.min, d.max), -r, r, b);
+        break;
+      }
+      case RT355_CONE: {
+        if (cones_unbounded || !std::isfinite(d.min) || !std::isfinite(d.max)) {
+          p.bounded = false;
+          break;
+        }
+        // walls: x^2+z^2 = y^2 + q with |q| <= 0.005/(4|a|), |a| > EPSILON, because the discriminant is
+        // rounded to 2 decimals (src/shape.rs:300); caps accept r^2 + EPSILON (src/shape.rs:474-478).
+        double ym = std::max(std::fabs((double)d.min), std::fabs((double)d.max));
+        double r = std::sqrt(ym * ym + 0.005 / (4 * EPS_F) + EPS_F) * (1 + 1e-6);
+        box_of_local(d.m, -r, r, std::min(d.min, d.max), std::max(d.min, d.max), -r, r, b);
+        break;
+      }
+      case RT355_TRIANGLE:
+      case RT355_SMOOTH_TRIANGLE: {
+        for (int k = 0; k < 3; ++k) {
+          if (!std::isfinite(d.p1[k]) || !std::isfinite(d.p2[k]) || !std::isfinite(d.p3[k])) return fail("non-finite vertex", i);
+          p.p1[k] = d.p1[k];
+          p.e1[k] = (double)d.p2[k] - (double)d.p1[k];
+          p.e2[k] = (double)d.p3[k] - (double)d.p1[k];
+          p.n1[k] = d.n1[k], p.n2[k] = d.n2[k], p.n3[k] = d.n3[k];
+        }
+        // flat normal: local e2 = p3 - p2, local e1 = p2 - p1, normal = normalize(e2 x e1)
+        double a[3], c[3];
+        for (int k = 0; k < 3; ++k) a[k] = (double)d.p3[k] - (double)d.p2[k], c[k] = (double)d.p2[k] - (double)d.p1[k];
+        double nx = a[1] * c[2] - a[2] * c[1], ny = a[2] * c[0] - a[0] * c[2], nz = a[0] * c[1] - a[1] * c[0];
+        double len = std::sqrt(nx * nx + ny * ny + nz * nz);
+        p.nf[0] = nx / len, p.nf[1] = ny / len, p.nf[2] = nz / len;  // zero-area triangle: NaN, as in the reference
+        double q1[3] = {d.p1[0], d.p1[1], d.p1[2]}, q2[3] = {d.p2[0], d.p2[1], d.p2[2]}, q3[3] = {d.p3[0], d.p3[1], d.p3[2]}, w[3];
+        xf_point(d.m, q1, w), b.grow(w);
+        xf_point(d.m, q2, w), b.grow(w);
+        xf_point(d.m, q3, w), b.grow(w);
+        break;
+      }
+    }
+    if (p.bounded) {
+      for (int k = 0; k < 3; ++k)
+        if (!std::isfinite(b.lo[k]) || !std::isfinite(b.hi[k])) p.bounded = false;
+    }
+    if (p.bounded) {
+      for (int k = 0; k < 3; ++k) {
+        double mag = std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k])) + (b.hi[k] - b.lo[k]);
+        double pad = pad_rel * mag + 1e-300;
+        p.lo[k] = b.lo[k] - pad, p.hi[k] = b.hi[k] + pad;
+      }
+      bounded.push_back(p);
+    } else {
+      unbounded.push_back(p);
+    }
+  }
+  if (out.materials.size() >= (1u << 23)) {
+    snprintf(err, errlen, "too many distinct materials");
+    return RT355_EINVAL;
+  }
+  if (bounded.size() >= (1u << 26)) {
+    snprintf(err, errlen, "too many shapes");
+    return RT355_EINVAL;
+  }
+
+  // ---- BVH over the bounded prims ---------------------------------------------------------------
+  out.n_bounded = (int32_t)bounded.size();
+  if (!bounded.empty()) {
+    Builder B(bounded);
+    size_t nb = bounded.size();
+    B.boxes.resize(nb), B.cx.resize(nb), B.cy.resize(nb), B.cz.resize(nb), B.order.resize(nb);
+    for (size_t i = 0; i < nb; ++i) {
+      for (int k = 0; k < 3; ++k) B.boxes[i].lo[k] = bounded[i].lo[k], B.boxes[i].hi[k] = bounded[i].hi[k];
+      B.cx[i] = 0.5 * (bounded[i].lo[0] + bounded[i].hi[0]);
+      B.cy[i] = 0.5 * (bounded[i].lo[1] + bounded[i].hi[1]);
+      B.cz[i] = 0.5 * (bounded[i].lo[2] + bounded[i].hi[2]);
+      B.order[i] = (int)i;
+    }
+    B.nodes.reserve(2 * nb);
+    int root = B.build(0, (int)nb, 0);
+    out.max_depth = B.max_depth + 1;
+    // reorder prims into leaf order
+    out.prims.reserve(nb + unbounded.size());
+    for (size_t k = 0; k < nb; ++k) out.prims.push_back(bounded[B.order[k]]);
+    // emit device nodes in DFS order; every inner build node becomes one device node
+    auto child_ref = [&](int bn, std::vector<int>& map) -> int32_t {
+      const BuildNode& c = B.nodes[bn];
+      if (c.left < 0) return encode_leaf(c.first, c.count);
+      return map[bn];
+    };
+    std::vector<int> map(B.nodes.size(), -1);
+    // first pass: assign indices in DFS order
+    std::vector<int> stack{root};
+    std::vector<int> dfs;
+    while (!stack.empty()) {
+      int bn = stack.back();
+      stack.pop_back();
+      if (B.nodes[bn].left < 0) continue;
+      map[bn] = (int)dfs.size();
+      dfs.push_back(bn);
+      stack.push_back(B.nodes[bn].right);
+      stack.push_back(B.nodes[bn].left);
+    }
+    auto empty_box = [](double* lo, double* hi) {
+      for (int k = 0; k < 3; ++k) lo[k] = INFINITY, hi[k] = -INFINITY;
+    };
+    if (dfs.empty()) {
+      // the root is a leaf: wrap it in one node whose second child is empty
+      HostNode hn;
+      for (int k = 0; k < 3; ++k) hn.lo0[k] = B.nodes[root].box.lo[k], hn.hi0[k] = B.nodes[root].box.hi[k];
+      empty_box(hn.lo1, hn.hi1);
+      hn.c0 = encode_leaf(B.nodes[root].first, B.nodes[root].count);
+      hn.c1 = encode_leaf(0, 0);
+      out.nodes.push_back(hn);
+    } else {
+      for (int bn : dfs) {
+        const BuildNode& l = B.nodes[B.nodes[bn].left];
+        const BuildNode& r = B.nodes[B.nodes[bn].right];
+        HostNode hn;
+        for (int k = 0; k < 3; ++k) {
+          hn.lo0[k] = l.box.lo[k], hn.hi0[k] = l.box.hi[k];
+          hn.lo1[k] = r.box.lo[k], hn.hi1[k] = r.box.hi[k];
+        }
+        hn.c0 = child_ref(B.nodes[bn].left, map);
+        hn.c1 = child_ref(B.nodes[bn].right, map);
+        out.nodes.push_back(hn);
+      }
+    }
+  }
+  for (auto& p : unbounded) out.prims.push_back(p);
+  if (out.max_depth > STACK_DEPTH - 2) {
+    snprintf(err, errlen, "BVH too deep (%d)", out.max_depth);
+    return RT355_EINVAL;
+  }
+  return RT355_OK;
+}
+
+}  // namespace rt355

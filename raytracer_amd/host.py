@@ -304,6 +304,9 @@ class Device:
     def set_pool(self, rays_per_pixel):
         _abi.check(self.lib.rt355_ctx_set_pool(self.handle, float(rays_per_pixel)))
 
+    def set_exact_cones(self, mode):
+        _abi.check(self.lib.rt355_ctx_set_exact_cones(self.handle, int(mode)))
+
     def set_counting(self, on):
         _abi.check(self.lib.rt355_ctx_set_counting(self.handle, int(bool(on))))
 

@@ -108,7 +108,9 @@ def glass(width=1920, height=1080):
     (src/intersection.rs:370-422)."""
     floor = Shape.Plane(None, Material(color=(1.0, 0.9, 0.9), specular=0.0, shininess=0.0, reflective=0.3,
                                        pattern=Pattern.Checker((1, 1, 1), (0, 0, 0))))
-    back_wall = Shape.Plane(mx.translation(0, 0, 10) @ mx.rotation_x(PI / 2), Material(color=(0.8, 0.8, 0.8), reflective=0.5))
+    # a slab, not a rotated Plane: the reference returns a plane's object-space normal untransformed
+    # (src/shape.rs:144), so a rotated plane self-shadows at random (its over_point never leaves it)
+    back_wall = Shape.Cube(mx.translation(0, 0, 10.1) @ mx.scaling(30.0, 30.0, 0.1), Material(color=(0.8, 0.8, 0.8), reflective=0.5))
     g = Material.new_glass()
     g.reflective = 0.9
     g.ambient, g.diffuse = 0.02, 0.1
@@ -167,24 +169,26 @@ class BulkWorld(World):
         return (_abi.ShapeDesc * self.n_shapes()).from_buffer(self.records)
 
 
-def stress(width=7680, height=4320, n_top=10, n_mid=100, n_leaf=100):
+def stress(width=7680, height=4320, n_top=10, n_mid=100, n_leaf=100, extent=400.0):
     """Config 5: n_top*n_mid*n_leaf instances (25 % each cube / closed cylinder 0..1 / closed cone -1..0 /
     sphere) in a 3-level group tree, flattened with the reference's one-level composition
     (src/group.rs:130-168): a leaf gets mid_group.transformation * leaf.transformation and the top
     groups' transformations do not accumulate.  Group entries stay in the list as inert shapes.
-    Positions are uniform in a 400 x 40 x 400 slab, scale 0.3-0.8, random Y rotation, 10 % reflective."""
+    Positions are uniform in an extent x 40 x extent slab (400 by default), scale 0.3-0.8, random Y
+    rotation, 10 % reflective."""
     n_groups_mid = n_top * n_mid
     n = n_groups_mid * n_leaf
     u = _splitmix64(n * 8 + n_groups_mid * 2)
     ul = u[: n * 8].reshape(n, 8)
     ug = u[n * 8:].reshape(n_groups_mid, 2)
-    # mid groups on a grid covering x,z in [-200,200)
+    # mid groups on a grid covering x,z in [-extent/2, extent/2)
+    half = extent / 2.0
     gx_n = int(math.ceil(math.sqrt(n_groups_mid)))
     gz_n = int(math.ceil(n_groups_mid / gx_n))
-    cell_x, cell_z = 400.0 / gx_n, 400.0 / gz_n
+    cell_x, cell_z = extent / gx_n, extent / gz_n
     gid = np.arange(n_groups_mid)
-    g_tx = -200.0 + (gid % gx_n) * cell_x + 0.1 * ug[:, 0]
-    g_tz = -200.0 + (gid // gx_n) * cell_z + 0.1 * ug[:, 1]
+    g_tx = -half + (gid % gx_n) * cell_x + 0.1 * ug[:, 0]
+    g_tz = -half + (gid // gx_n) * cell_z + 0.1 * ug[:, 1]
 
     total = 1 + n_top + n_groups_mid + n + 1  # root, tops, mids, leaves, floor
     rec = np.zeros(total, dtype=shape_dtype())
@@ -196,7 +200,6 @@ def stress(width=7680, height=4320, n_top=10, n_mid=100, n_leaf=100):
     rec["min"], rec["max"] = -np.inf, np.inf
 
     # depth-first order: root, then per top group: top, then per mid: mid, leaves
-    order = np.empty(total - 1, dtype=np.int64)  # not needed explicitly; fill sequentially below
     pos = 0
     rec["kind"][pos] = _abi.GROUP
     pos += 1
@@ -228,7 +231,7 @@ def stress(width=7680, height=4320, n_top=10, n_mid=100, n_leaf=100):
     kinds = kind_cycle[np.arange(n) % 4]
     s = 0.3 + 0.5 * ul[:, 0]
     ang = 2 * PI * ul[:, 1]
-    lx, ly, lz = cell_x * ul[:, 2], 1.0 + 38.0 * ul[:, 3], cell_z * ul[:, 4]
+    lx, ly, lz = cell_x * ul[:, 2], 1.0 + min(38.0, extent / 10.0 - 2.0) * ul[:, 3], cell_z * ul[:, 4]
     c, sn = np.cos(ang), np.sin(ang)
     leaf = np.tile(np.eye(4, dtype=np.float64), (n, 1, 1))
     # translation * rotation_y * scaling
@@ -253,8 +256,9 @@ def stress(width=7680, height=4320, n_top=10, n_mid=100, n_leaf=100):
     rec["kind"][floor_slot] = _abi.PLANE
     rec["mat"]["color"][floor_slot] = (0.9, 0.9, 0.9)
     rec["mat"]["specular"][floor_slot] = 0.1
-    world = BulkWorld(PointLight((-150.0, 400.0, -300.0), (1, 1, 1)), rec)
-    return world, _camera(width, height, PI / 3.0, (0.0, 140.0, -420.0), (0.0, 10.0, 0.0), (0.0, 1.0, 0.0))
+    k = extent / 400.0
+    world = BulkWorld(PointLight((-150.0 * k, 400.0 * k, -300.0 * k), (1, 1, 1)), rec)
+    return world, _camera(width, height, PI / 3.0, (0.0, 140.0 * k, -420.0 * k), (0.0, 10.0 * k, 0.0), (0.0, 1.0, 0.0))
 
 
 def stress_tree(n_top=2, n_mid=3, n_leaf=4):
