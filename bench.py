@@ -1,0 +1,190 @@
+"""Headline benchmark: Mrays/s (primary + secondary + shadow rays) of `Camera::render` on the north-star
+workload -- teapot-high (6 320 smooth triangles) on a reflective checker floor next to a glass sphere,
+shadows, reflection / refraction depth 5, 1920x1080 -- on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is ONE frame: every rank renders its 32x32 tiles (tile t -> rank t % N, scene replicated), the
+rank tile buffers are gathered to rank 0 (torch.distributed.gather = RCCL over xGMI) and un-tiled there.
+The scene is uploaded once, before the timed region; all inputs are resident in HBM when timing starts.
+Rank 0 prints one JSON line.  `value` counts the rays actually traced: one radiance ray per color_at
+call plus one shadow ray per hit (src/world.rs:58-66, :105), summed over all ranks.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from raytracer_amd import Device, _abi, scenes  # noqa: E402
+from raytracer_amd import dist as rd  # noqa: E402
+from raytracer_amd._abi import Stats  # noqa: E402
+
+FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 (FMA) x 2.4 GHz
+KIND_NAME = {1: "k_trace", 2: "k_shade", 3: "k_combine"}
+
+
+def cpu_baseline(world, cam, depth):
+    """The CPU restatement of the reference path (oracle/, float = the reference's precision, brute
+    force, recursive, 1 thread like the reference) on a bounded window of the same frame."""
+    import oracle
+    w, h = int(cam.horizontal_size), int(cam.vertical_size)
+    ww, wh = max(1, w // 4), max(1, h // 4)
+    x0, y0 = (w - ww) // 2, int(h * 0.55) - wh // 2
+    _, cnt, sec = oracle.render(world, cam, depth, 32, 0, (x0, x0 + ww, y0, y0 + wh), threads=1)
+    rays = int(cnt["radiance"].sum() + cnt["hits"].sum())
+    return {"value": round(rays / sec / 1e6, 6), "unit": "Mrays/s", "cores": 1, "kind": "port",
+            "sample": f"{ww}x{wh} pixel window at ({x0},{y0}) of the same {w}x{h} frame, {rays} rays, "
+                      f"{sec:.1f} s, float, brute force over {world.n_shapes()} shapes, 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scene", default="north_star")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--depth", type=int, default=5)
+    ap.add_argument("--real", type=int, default=64, choices=[32, 64])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world_size = int(os.environ.get("WORLD_SIZE", 1))
+    if world_size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    if world_size > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    world, cam = scenes.CONFIGS[args.scene](args.width, args.height)
+    w, h = args.width, args.height
+    dev = Device.get(local_rank, args.real)
+    scene = dev.upload(world)  # once, outside the timed region
+    tpr = rd.tiles_per_rank(w, h, world_size)
+    local = torch.empty(tpr * rd.TILE * rd.TILE * 3, dtype=torch.float32, device="cuda")
+    gathered = torch.empty((world_size, local.numel()), dtype=torch.float32, device="cuda") if rank == 0 else None
+    canvas = torch.empty((h, w, 3), dtype=torch.float32, device="cuda") if rank == 0 else None
+    bufs = list(gathered.unbind(0)) if rank == 0 else None
+    st = Stats()
+
+    def step():
+        rd.render_tiles(scene, cam, args.depth, rank, world_size, local, st)
+        if world_size > 1:
+            dist.gather(local, bufs, dst=0)
+            src = gathered
+        else:
+            src = local
+        if rank == 0:
+            rd.untile(dev, cam, world_size, src, canvas)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    rays_local = int(st.total_radiance + st.total_shadow) - (int(st.radiance_rays[0]) - _active_pixels(w, h, rank, world_size))
+    primary_local = _active_pixels(w, h, rank, world_size)
+
+    tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    rr = torch.tensor([rays_local, primary_local], dtype=torch.int64, device="cuda")
+    if world_size > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+    elapsed = float(tt.item())
+    rays_frame, primary_frame = int(rr[0].item()), int(rr[1].item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        out = {
+            "metric": "Mrays/sec (primary+secondary) on teapot-high 1920x1080",
+            "value": round(rays_frame / (ms * 1e-3) / 1e6, 3),
+            "unit": "Mrays/s",
+            "n_gpus": world_size,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64" if args.real == 64 else "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.scene} {w}x{h} depth {args.depth}: teapot-high.obj (6320 smooth triangles) + "
+                                   "reflective checker floor + glass sphere, shadows" if args.scene == "north_star"
+                       else f"{args.scene} {w}x{h} depth {args.depth}",
+                       "shapes": world.n_shapes(), "rays_per_frame": rays_frame, "primary_rays_per_frame": primary_frame,
+                       "primary_mrays_per_s": round(primary_frame / (ms * 1e-3) / 1e6, 3),
+                       "parallelism": f"tile{world_size}", "bvh": scene.info()},
+        }
+        # --- roofline of the dominant kernel: separate frames, never inside the timed region above ----
+        dev.set_timing(True)
+        n_prof = 5
+        acc = None
+        for _ in range(n_prof):
+            rd.render_tiles(scene, cam, args.depth, rank, world_size, local, st)
+            ms_l = np.array(st.launch_ms[: st.n_launch], dtype=np.float64)
+            acc = ms_l if acc is None else acc + ms_l
+        dev.set_timing(False)
+        ms_l = acc / n_prof
+        dev.set_counting(True)
+        rd.render_tiles(scene, cam, args.depth, rank, world_size, local, st)
+        dev.set_counting(False)
+        flops = np.array(st.launch_flops[: st.n_launch], dtype=np.float64)
+        kinds = list(st.launch_kind[: st.n_launch])
+        gens = list(st.launch_gen[: st.n_launch])
+        k = int(np.argmax(ms_l))
+        achieved = flops[k] / (ms_l[k] * 1e-3) / 1e12
+        out["roofline"] = {
+            "bound": "valu_fp64" if args.real == 64 else "valu_fp32",
+            "kernel": f"{KIND_NAME.get(kinds[k], '?')} generation {gens[k]}",
+            "achieved": round(achieved, 4),
+            "peak": FP64_VALU_PEAK_TFLOPS if args.real == 64 else 2 * FP64_VALU_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": round(achieved / (FP64_VALU_PEAK_TFLOPS if args.real == 64 else 2 * FP64_VALU_PEAK_TFLOPS), 5),
+            "traffic": None,
+            "flops_per_launch": float(flops[k]),
+            "launch_ms": round(float(ms_l[k]), 4),
+            "frame_flops": float(flops.sum()),
+            "frame_kernel_ms": round(float(ms_l.sum()), 4),
+            "frame_frac": round(float(flops.sum() / (ms_l.sum() * 1e-3) / 1e12 / (FP64_VALU_PEAK_TFLOPS if args.real == 64 else 2 * FP64_VALU_PEAK_TFLOPS)), 5),
+            "launches": [{"kernel": KIND_NAME.get(kinds[i], "?"), "gen": gens[i], "ms": round(float(ms_l[i]), 4),
+                          "gflop": round(float(flops[i]) / 1e9, 4)} for i in range(len(kinds))],
+        }
+        if not args.no_cpu_baseline and world_size == 1:
+            out["cpu_baseline"] = cpu_baseline(world, cam, args.depth)
+        print(json.dumps(out))
+    if world_size > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _active_pixels(w, h, rank, world_size):
+    """Pixels of the frame this rank owns (its tile slots minus padding)."""
+    idx = rd.tile_pixels(w, h, rank, world_size)
+    return int((idx >= 0).sum())
+
+
+if __name__ == "__main__":
+    main()

@@ -97,21 +97,8 @@ RT_FN void prim_hits(const DevScene<R>& sc, int p, int flags, V3<R> wo, V3<R> wd
   }
   const R EPS = eps<R>();
   if (kind >= RT355_TRIANGLE) {
-    // src/shape.rs:328-375 (Moeller-Trumbore)
-    const DevTri<R>& T = sc.tri[p];
-    V3<R> e1 = ld3(T.e1), e2 = ld3(T.e2), p1 = ld3(T.p1);
-    V3<R> dir_cross_e2 = cross(d, e2);
-    R det = dot(e1, dir_cross_e2);
-    if (approx_zero(fabs(det))) return;
-    R f = R(1) / det;
-    V3<R> p1_to_origin = o - p1;
-    R u = f * dot(p1_to_origin, dir_cross_e2);
-    if (u < R(0) || u > R(1)) return;
-    V3<R> origin_cross_e1 = cross(p1_to_origin, e1);
-    R v = f * dot(d, origin_cross_e1);
-    if (v < R(0) || (u + v) > R(1)) return;
-    R t = f * dot(e2, origin_cross_e1);
-    emit(t, u, v, 0);
+    R t, u, v;
+    if (tri_hit(sc.tri[p], o, d, t, u, v)) emit(t, u, v, 0);
     return;
   }
   switch (kind) {
@@ -148,7 +135,6 @@ RT_FN void prim_hits(const DevScene<R>& sc, int p, int flags, V3<R> wo, V3<R> wd
       const R ymin = sc.xform[p].ymin, ymax = sc.xform[p].ymax;
       const bool cone = kind == RT355_CONE;
       int em = 0;
-      bool walls_done = false;
       if (!cone) {
         R a = d.x * d.x + d.z * d.z;
         if (!approx_zero(a)) {
@@ -164,7 +150,6 @@ RT_FN void prim_hits(const DevScene<R>& sc, int p, int flags, V3<R> wo, V3<R> wd
           R y1 = o.y + t1 * d.y;
           if (ymin < y1 && y1 < ymax) emit(t1, R(0), R(0), em++);
         }
-        walls_done = true;
       } else {
         R a = d.x * d.x - d.y * d.y + d.z * d.z;
         R b = R(2) * (o.x * d.x - o.y * d.y + o.z * d.z);
@@ -183,9 +168,7 @@ RT_FN void prim_hits(const DevScene<R>& sc, int p, int flags, V3<R> wo, V3<R> wd
           R y1 = o.y + t1 * d.y;
           if (ymin < y1 && y1 < ymax) emit(t1, R(0), R(0), em++);
         }
-        walls_done = true;
       }
-      (void)walls_done;
       // intersect_caps (src/shape.rs:480-514)
       if (!(flags & PF_CLOSED) || approx_zero(d.y)) return;
       R t_lower = (ymin - o.y) / d.y;
@@ -207,21 +190,44 @@ RT_FN void prim_hits(const DevScene<R>& sc, int p, int flags, V3<R> wo, V3<R> wd
 }
 
 // ------------------------------------------------------------------------------------------------
-// BVH traversal.  Visitor: tmin(), tmax() give the live ray interval; prim(p) tests one prim and returns
-// true to stop.  Replaces the brute-force loop of World::intersect (src/world.rs:35-44).
+// Moeller-Trumbore on one triangle record (src/shape.rs:328-375); the ray is already in object space.
+// ------------------------------------------------------------------------------------------------
+template <class R>
+RT_FN bool tri_hit(const DevTri<R>& T, V3<R> o, V3<R> d, R& t, R& u, R& v) {
+  const V3<R> e1 = ld3(T.e1), e2 = ld3(T.e2), p1 = ld3(T.p1);
+  const V3<R> dir_cross_e2 = cross(d, e2);
+  const R det = dot(e1, dir_cross_e2);
+  if (approx_zero(fabs(det))) return false;
+  const R f = R(1) / det;
+  const V3<R> p1_to_origin = o - p1;
+  u = f * dot(p1_to_origin, dir_cross_e2);
+  if (u < R(0) || u > R(1)) return false;
+  const V3<R> origin_cross_e1 = cross(p1_to_origin, e1);
+  v = f * dot(d, origin_cross_e1);
+  if (v < R(0) || (u + v) > R(1)) return false;
+  t = f * dot(e2, origin_cross_e1);
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BVH traversal.  Replaces the brute-force loop of World::intersect (src/world.rs:35-44).
+// Visitor: tmin(), tmax() give the live ray interval; prim(p) tests one prim of any kind, tri(p, T) one
+// identity-transform triangle whose record is already loaded; both return true to stop.
+// The stack lives in LDS, one column per lane (lds[k * BLOCK]), so a push / pop is a conflict-free
+// ds_write / ds_read instead of a scratch round trip; entries beyond LDS_STACK spill to scratch.
 // ------------------------------------------------------------------------------------------------
 template <class R, bool COUNT, class Vis>
-RT_FN void traverse(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work& wk) {
+RT_FN void traverse(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work& wk, int* lds) {
   for (int p = sc.n_bounded; p < sc.n_prims; ++p)
     if (vis.prim(p)) return;
   if (sc.n_nodes == 0) return;
   const V3<R> id = {R(1) / d.x, R(1) / d.y, R(1) / d.z};
-  int stack[STACK_DEPTH];
+  int spill[STACK_DEPTH - LDS_STACK];
   int sp = 0;
   int cur = 0;
   for (;;) {
     if (cur >= 0) {
-      const BvhNode<R>& N = sc.nodes[cur];
+      const BvhNode<R> N = sc.nodes[cur];
       const R tmin = vis.tmin(), tmax = vis.tmax();
       R ax0 = (N.lo0[0] - o.x) * id.x, ax1 = (N.hi0[0] - o.x) * id.x;
       R ay0 = (N.lo0[1] - o.y) * id.y, ay1 = (N.hi0[1] - o.y) * id.y;
@@ -238,7 +244,9 @@ RT_FN void traverse(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work& wk)
       if constexpr (COUNT) wk.box += 2;
       if (ha && hb) {
         const bool a_first = an <= bn;
-        stack[sp++] = a_first ? c1 : c0;
+        const int far = a_first ? c1 : c0;
+        if (sp < LDS_STACK) lds[sp * BLOCK] = far; else spill[sp - LDS_STACK] = far;
+        ++sp;
         cur = a_first ? c0 : c1;
         continue;
       }
@@ -246,12 +254,104 @@ RT_FN void traverse(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work& wk)
       if (hb) { cur = c1; continue; }
     } else {
       const uint32_t leaf = (uint32_t)~cur;
-      const int first = (int)(leaf & 0x3FFFFFFu), count = (int)(leaf >> 26);
-      for (int k = 0; k < count; ++k)
-        if (vis.prim(first + k)) return;
+      const int first = (int)(leaf & LEAF_FIRST_MASK), count = (int)(leaf >> 26);
+      if (leaf & LEAF_TRI_BIT) {
+        for (int k = 0; k < count; ++k) {
+          const DevTri<R> T = sc.tri[first + k];
+          if constexpr (COUNT) wk.prim[T.flags & PF_KIND_MASK]++;
+          if (vis.tri(first + k, T)) return;
+        }
+      } else {
+        for (int k = 0; k < count; ++k)
+          if (vis.prim(first + k)) return;
+      }
     }
     if (sp == 0) return;
-    cur = stack[--sp];
+    --sp;
+    cur = sp < LDS_STACK ? lds[sp * BLOCK] : spill[sp - LDS_STACK];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Packet traversal: the 64 rays of a wave walk the BVH TOGETHER.  The current node, the stack and every
+// branch are wave-uniform, so node and triangle records come in through scalar loads (one request per
+// wave instead of 64 divergent 112-byte fetches) and the vector ALU does nothing but slab and triangle
+// arithmetic.  A child is entered when ANY live lane's ray overlaps its box; the near child is the one
+// most lanes want first.  Every lane tests every triangle of a visited leaf against its own interval, so
+// each lane still finds exactly its own nearest / any hit.  Good for coherent rays (primary, shadow,
+// mirror reflections); incoherent generations use the per-lane traverse above.
+// All 64 lanes must call this together; `live` is false for lanes without a ray.
+// ------------------------------------------------------------------------------------------------
+template <class T> using cptr = const __attribute__((address_space(4))) T*;
+
+template <class R>
+RT_FN DevTri<R> load_tri_uniform(const DevScene<R>& sc, int p) {
+  DevTri<R> T;
+  cptr<R> q = (cptr<R>)(const R*)&sc.tri[p];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) T.p1[k] = q[k], T.e1[k] = q[3 + k], T.e2[k] = q[6 + k];
+  cptr<int32_t> qi = (cptr<int32_t>)(const int32_t*)&sc.tri[p].shape;
+  T.shape = qi[0], T.flags = qi[1];
+  return T;
+}
+
+template <class R, bool COUNT, class Vis>
+RT_FN void traverse_packet(const DevScene<R>& sc, V3<R> o, V3<R> d, bool live, Vis& vis, Work& wk, int* wstack) {
+  for (int p = sc.n_bounded; p < sc.n_prims; ++p)
+    if (live && vis.prim(p)) live = false;
+  if (sc.n_nodes == 0) return;
+  const V3<R> id = {R(1) / d.x, R(1) / d.y, R(1) / d.z};
+  const V3<R> oid = {o.x * id.x, o.y * id.y, o.z * id.z};
+  int sp = 0;
+  int cur = 0;
+  for (;;) {
+    if (__ballot(live) == 0ull) return;
+    if (cur >= 0) {
+      cptr<R> q = (cptr<R>)(const R*)&sc.nodes[cur];
+      cptr<int32_t> qc = (cptr<int32_t>)(const int32_t*)&sc.nodes[cur].c0;
+      const int c0 = qc[0], c1 = qc[1];
+      const R tmin = vis.tmin(), tmax = vis.tmax();
+      // (lo - o) * id == lo * id - o * id up to rounding; boxes are padded by far more than that
+      R ax0 = q[0] * id.x - oid.x, ax1 = q[3] * id.x - oid.x;
+      R ay0 = q[1] * id.y - oid.y, ay1 = q[4] * id.y - oid.y;
+      R az0 = q[2] * id.z - oid.z, az1 = q[5] * id.z - oid.z;
+      R an = fmax(fmax(fmin(ax0, ax1), fmin(ay0, ay1)), fmax(fmin(az0, az1), tmin));
+      R af = fmin(fmin(fmax(ax0, ax1), fmax(ay0, ay1)), fmin(fmax(az0, az1), tmax));
+      R bx0 = q[6] * id.x - oid.x, bx1 = q[9] * id.x - oid.x;
+      R by0 = q[7] * id.y - oid.y, by1 = q[10] * id.y - oid.y;
+      R bz0 = q[8] * id.z - oid.z, bz1 = q[11] * id.z - oid.z;
+      R bn = fmax(fmax(fmin(bx0, bx1), fmin(by0, by1)), fmax(fmin(bz0, bz1), tmin));
+      R bf = fmin(fmin(fmax(bx0, bx1), fmax(by0, by1)), fmin(fmax(bz0, bz1), tmax));
+      const bool ha = live && an <= af, hb = live && bn <= bf;
+      if constexpr (COUNT) wk.box += live ? 2 : 0;
+      const unsigned long long ua = __ballot(ha), ub = __ballot(hb);
+      if (ua && ub) {
+        const bool a_first = __popcll(__ballot(ha && (!hb || an <= bn))) >= __popcll(__ballot(hb && (!ha || bn < an)));
+        const int far = a_first ? c1 : c0;
+        wstack[sp++] = far;
+        cur = a_first ? c0 : c1;
+        continue;
+      }
+      if (ua) { cur = c0; continue; }
+      if (ub) { cur = c1; continue; }
+    } else {
+      const uint32_t leaf = (uint32_t)~cur;
+      const int first = (int)(leaf & LEAF_FIRST_MASK), count = (int)(leaf >> 26);
+      if (leaf & LEAF_TRI_BIT) {
+        for (int k = 0; k < count; ++k) {
+          const DevTri<R> T = load_tri_uniform(sc, first + k);
+          if (live) {
+            if constexpr (COUNT) wk.prim[T.flags & PF_KIND_MASK]++;
+            if (vis.tri(first + k, T)) live = false;
+          }
+        }
+      } else {
+        for (int k = 0; k < count; ++k)
+          if (live && vis.prim(first + k)) live = false;
+      }
+    }
+    if (sp == 0) return;
+    cur = __builtin_amdgcn_readfirstlane(wstack[--sp]);
   }
 }
 
@@ -268,13 +368,17 @@ struct ClosestVis {
       : sc(s), o(o_), d(d_), wk(w), best_t(inf<R>()), best_u(0), best_v(0), best_p(-1), best_s(0x7fffffff) {}
   RT_FN R tmin() const { return R(0); }
   RT_FN R tmax() const { return best_t; }
+  RT_FN void accept(R t, R u, R v, int p, int shape) {
+    if (t >= R(0) && (t < best_t || (t == best_t && shape < best_s))) best_t = t, best_u = u, best_v = v, best_p = p, best_s = shape;
+  }
   RT_FN bool prim(int p) {
     const PrimInfo info = sc.prim_info[p];
-    prim_hits<R, COUNT>(sc, p, info.flags, o, d, wk, [&](R t, R u, R v, int) {
-      if (t >= R(0) && (t < best_t || (t == best_t && info.shape < best_s))) {
-        best_t = t, best_u = u, best_v = v, best_p = p, best_s = info.shape;
-      }
-    });
+    prim_hits<R, COUNT>(sc, p, info.flags, o, d, wk, [&](R t, R u, R v, int) { accept(t, u, v, p, info.shape); });
+    return false;
+  }
+  RT_FN bool tri(int p, const DevTri<R>& T) {
+    R t, u, v;
+    if (tri_hit(T, o, d, t, u, v)) accept(t, u, v, p, T.shape);
     return false;
   }
 };
@@ -295,6 +399,11 @@ struct AnyVis {
     prim_hits<R, COUNT>(sc, p, info.flags, o, d, wk, [&](R t, R, R, int) {
       if (t >= R(0) && t < limit) found = true;
     });
+    return found;
+  }
+  RT_FN bool tri(int, const DevTri<R>& T) {
+    R t, u, v;
+    if (tri_hit(T, o, d, t, u, v) && t >= R(0) && t < limit) found = true;
     return found;
   }
 };
@@ -319,48 +428,46 @@ struct ContainerVis {
       : sc(s), o(o_), d(d_), wk(w), t_hit(th), s_hit(sh), p_hit(ph), have(false), bt(0), bs(-1), bflags(0) {}
   RT_FN R tmin() const { return -inf<R>(); }
   RT_FN R tmax() const { return t_hit; }
+  RT_FN bool before(R t, int shape) const { return t < t_hit || (t == t_hit && shape < s_hit); }
+  RT_FN void present(R mt, int shape, int flags) {
+    if (!have || mt > bt || (mt == bt && shape > bs)) have = true, bt = mt, bs = shape, bflags = flags;
+  }
   RT_FN bool prim(int p) {
     if (p == p_hit) return false;
     const PrimInfo info = sc.prim_info[p];
     int cnt = 0;
     R mt = R(0);
     prim_hits<R, COUNT>(sc, p, info.flags, o, d, wk, [&](R t, R, R, int) {
-      if (t < t_hit || (t == t_hit && info.shape < s_hit)) {
+      if (before(t, info.shape)) {
         if (cnt == 0 || t > mt) mt = t;
         ++cnt;
       }
     });
-    if (cnt & 1) {
-      if (!have || mt > bt || (mt == bt && info.shape > bs)) have = true, bt = mt, bs = info.shape, bflags = info.flags;
-    }
+    if (cnt & 1) present(mt, info.shape, info.flags);
+    return false;
+  }
+  RT_FN bool tri(int p, const DevTri<R>& T) {
+    if (p == p_hit) return false;
+    R t, u, v;
+    if (tri_hit(T, o, d, t, u, v) && before(t, T.shape)) present(t, T.shape, T.flags);
     return false;
   }
 };
 
 // ------------------------------------------------------------------------------------------------
-// wave64 compaction: every active lane asks for `want` (0/1) slots of one kind and `want2` of another;
-// one atomic per wave.  Returns the wave's base; offsets are positions inside the wave's block.
+// Block-level compaction.  Each wave counts with __ballot / __popcll, the four wave totals meet in LDS,
+// and ONE lane per block touches the global counter: a single word takes fewer than 100 atomics per
+// microsecond on this chip, so one atomic per wave (32 400 for a 1080p frame) would by itself cost more
+// than the traversal.
 // ------------------------------------------------------------------------------------------------
-RT_FN uint32_t wave_alloc2(uint32_t* counter, bool want, bool want2, uint32_t& off1, uint32_t& off2) {
-  const unsigned long long m1 = __ballot(want), m2 = __ballot(want2), act = __ballot(1);
-  const int lane = __lane_id();
-  const int leader = __ffsll((long long)act) - 1;
-  const uint32_t n1 = __popcll(m1), n2 = __popcll(m2);
-  uint32_t base = 0;
-  if (lane == leader && (n1 + n2)) base = atomicAdd(counter, n1 + n2);
-  base = __shfl(base, leader);
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  off1 = __popcll(m1 & lt);
-  off2 = n1 + __popcll(m2 & lt);
-  return base;
-}
+RT_FN unsigned long long lanes_below() { return (1ull << (threadIdx.x & 63u)) - 1ull; }
 
 // Id range of generation `gen`: generations are stacked in the pool in order.  A generation that did
 // not fit is cut at the pool's capacity (the frame is then reported as RT355_ECAPACITY).
 RT_FN void gen_range(const FrameCtl* ctl, int gen, long long capacity, uint32_t& start, uint32_t& count) {
   unsigned long long s = 0;
-  for (int g = 0; g < gen; ++g) s += ctl->gen_count[g];
-  unsigned long long c = ctl->gen_count[gen];
+  for (int g = 0; g < gen; ++g) s += ctl->gen_count[g].v;
+  unsigned long long c = ctl->gen_count[gen].v;
   if (s > (unsigned long long)capacity) s = capacity;
   if (s + c > (unsigned long long)capacity) c = capacity - s;
   start = (uint32_t)s, count = (uint32_t)c;
@@ -406,30 +513,73 @@ __global__ void __launch_bounds__(256) k_gen_primary(DevCamera<R> cam, RayPool<R
 // ------------------------------------------------------------------------------------------------
 // k_trace: World::intersect + hit() for every ray of generation `gen`.
 // ------------------------------------------------------------------------------------------------
-template <class R, bool COUNT>
+template <class R, bool COUNT, bool PACKET>
 __global__ void __launch_bounds__(256) k_trace(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int launch) {
+  __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
+  __shared__ uint32_t s_cnt[CHUNK_K * (BLOCK / 64)];
+  int* lds = PACKET ? lds_stack + (threadIdx.x >> 6) * STACK_DEPTH : lds_stack + threadIdx.x;
   uint32_t start, count;
   gen_range(ctl, gen, pool.capacity, start, count);
-  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t n_chunks = (count + CHUNK - 1) / CHUNK;
+  const uint32_t wave = threadIdx.x >> 6;
+  uint32_t* chunk_hits = pool.chunk_hits + (size_t)gen * pool.chunks_per_gen;
   Work wk;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-    const uint32_t r = start + i;
-    const V3<R> o = ld3(pool.org + 3ull * r), d = ld3(pool.dir + 3ull * r);
-    ClosestVis<R, COUNT> vis(sc, o, d, wk);
-    const bool live = !(d.x == R(0) && d.y == R(0) && d.z == R(0));
-    if (live) traverse<R, COUNT>(sc, o, d, vis, wk);
-    const bool hit = vis.best_p >= 0;
-    pool.hit_prim[r] = vis.best_p;
-    if (hit) {
-      pool.hit_t[r] = vis.best_t;
-      pool.hit_uv[2ull * r] = vis.best_u;
-      pool.hit_uv[2ull * r + 1] = vis.best_v;
-    } else {
-      st3(pool.color + 3ull * r, mk<R>(R(0), R(0), R(0)));  // world.rs:61-63: a miss is black
+  // block-uniform trip counts: every wave reaches the barriers, all 64 lanes stay converged for ballots
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const uint32_t base = chunk * CHUNK;
+    uint32_t hitbits = 0;
+#pragma unroll 1
+    for (int k = 0; k < CHUNK_K; ++k) {
+      const uint32_t i = base + k * BLOCK + threadIdx.x;
+      const bool valid = i < count;
+      const uint32_t r = start + (valid ? i : 0u);
+      const V3<R> o = ld3(pool.org + 3ull * r), d = ld3(pool.dir + 3ull * r);
+      ClosestVis<R, COUNT> vis(sc, o, d, wk);
+      const bool live = valid && !(d.x == R(0) && d.y == R(0) && d.z == R(0));
+      if constexpr (PACKET) {
+        traverse_packet<R, COUNT>(sc, o, d, live, vis, wk, lds);
+      } else {
+        if (live) traverse<R, COUNT>(sc, o, d, vis, wk, lds);
+      }
+      const bool hit = valid && vis.best_p >= 0;
+      if (valid) {
+        pool.hit_prim[r] = vis.best_p;
+        if (hit) {
+          pool.hit_t[r] = vis.best_t;
+          pool.hit_uv[2ull * r] = vis.best_u;
+          pool.hit_uv[2ull * r + 1] = vis.best_v;
+        } else {
+          st3(pool.color + 3ull * r, mk<R>(R(0), R(0), R(0)));  // world.rs:61-63: a miss is black
+        }
+      }
+      hitbits |= (hit ? 1u : 0u) << k;
     }
-    uint32_t off, off2;
-    const uint32_t base = wave_alloc2(&ctl->hit_count[gen], hit, false, off, off2);
-    if (hit) pool.hitlist[start + base + off] = (int32_t)r;
+    // hits of the chunk, in ray order, into the chunk's own hitlist slots
+    unsigned long long masks[CHUNK_K];
+#pragma unroll
+    for (int k = 0; k < CHUNK_K; ++k) {
+      masks[k] = __ballot((hitbits >> k) & 1u);
+      if ((threadIdx.x & 63u) == 0) s_cnt[k * (BLOCK / 64) + wave] = __popcll(masks[k]);
+    }
+    __syncthreads();
+    uint32_t total = 0;
+#pragma unroll
+    for (int k = 0; k < CHUNK_K; ++k) {
+      uint32_t before = total;
+#pragma unroll
+      for (int w = 0; w < BLOCK / 64; ++w) {
+        const uint32_t c = s_cnt[k * (BLOCK / 64) + w];
+        if (w < (int)wave) before += c;
+        total += c;
+      }
+      if ((hitbits >> k) & 1u)
+        pool.hitlist[(size_t)start + base + before + __popcll(masks[k] & lanes_below())] = (int32_t)(start + base + k * BLOCK + threadIdx.x);
+    }
+    if (threadIdx.x == 0) {
+      chunk_hits[chunk] = total;
+      if (total) atomicAdd(&ctl->hit_count[gen].v, total);
+    }
+    __syncthreads();
   }
   flush_work<COUNT>(ctl, launch, wk);
 }
@@ -535,17 +685,26 @@ RT_FN V3<R> lighting(const DevScene<R>& sc, const DevMaterial<R>& m, V3<R> point
 //   prepare_computation (src/intersection.rs:60-142), is_shadowed (src/world.rs:45-57), lighting,
 //   reflected_color / refracted_color ray set-up (src/world.rs:68-102), schlick (src/computation.rs:20-33).
 // ------------------------------------------------------------------------------------------------
-template <class R, bool COUNT>
+template <class R, bool COUNT, bool PACKET>
 __global__ void __launch_bounds__(256) k_shade(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch) {
   uint32_t start, gcount;
   gen_range(ctl, gen, pool.capacity, start, gcount);
-  const uint32_t nhit = ctl->hit_count[gen];
+  const uint32_t n_chunks = (gcount + CHUNK - 1) / CHUNK;
   const uint32_t child_start = start + gcount;
-  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t wave = threadIdx.x >> 6;
   const R EPS = eps<R>();
+  __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
+  __shared__ uint32_t s_cnt[BLOCK / 64];
+  __shared__ uint32_t s_base;
+  int* lds = PACKET ? lds_stack + (threadIdx.x >> 6) * STACK_DEPTH : lds_stack + threadIdx.x;
+  const uint32_t* chunk_hits = pool.chunk_hits + (size_t)gen * pool.chunks_per_gen;
   Work wk;
-  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nhit; j += stride) {
-    const uint32_t r = (uint32_t)pool.hitlist[start + j];
+  // block-uniform trip counts: every wave reaches the barriers, all 64 lanes stay converged for ballots
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x)
+  for (uint32_t nhit = chunk_hits[chunk], j0 = 0; j0 < nhit; j0 += BLOCK) {
+    const uint32_t j = j0 + threadIdx.x;
+    const bool valid = j < nhit;
+    const uint32_t r = (uint32_t)pool.hitlist[(size_t)start + (size_t)chunk * CHUNK + (valid ? j : 0u)];
     const V3<R> o = ld3(pool.org + 3ull * r), d = ld3(pool.dir + 3ull * r);
     const R t = pool.hit_t[r];
     const int p = pool.hit_prim[r];
@@ -566,29 +725,43 @@ __global__ void __launch_bounds__(256) k_shade(DevScene<R> sc, RayPool<R> pool, 
 
     const R reflective = m.reflective, transparency = m.transparency;
     R n1 = R(1), n2 = R(1);
-    if (transparency != R(0)) {
+    const bool need_n = valid && transparency != R(0);
+    if (PACKET ? (__ballot(need_n) != 0ull) : need_n) {
       // the hit shape's own intersections, emission order
-      R ht[4];
+      R ht[4] = {R(0), R(0), R(0), R(0)};
       int nh = 0;
-      prim_hits<R, COUNT>(sc, p, info.flags, o, d, wk, [&](R tt, R, R, int em) { if (em < 4) ht[em] = tt, nh = em + 1; });
+      if (need_n)
+        prim_hits<R, COUNT>(sc, p, info.flags, o, d, wk, [&](R tt, R, R, int em) {
+          if (em == 0) ht[0] = tt; else if (em == 1) ht[1] = tt; else if (em == 2) ht[2] = tt; else if (em == 3) ht[3] = tt;
+          nh = em + 1;
+        });
       // the entry the reference treats as "the hit" last: same t, latest emission
       int m_last = 0;
       R best = inf<R>();
+#pragma unroll
       for (int k = 0; k < 4; ++k)
         if (k < nh) {
           const R dd = fabs(ht[k] - t);
           if (dd <= best) best = dd, m_last = k;
         }
-      const R tm = nh ? ht[m_last] : t;
+      R tm = t;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (nh && k == m_last) tm = ht[k];
       int c_before = 0;
       R hmt = R(0);
+#pragma unroll
       for (int k = 0; k < 4; ++k)
         if (k < nh && (ht[k] < tm || (ht[k] == tm && k < m_last))) {
           if (c_before == 0 || ht[k] >= hmt) hmt = ht[k];
           ++c_before;
         }
       ContainerVis<R, COUNT> cv(sc, o, d, t, info.shape, p, wk);
-      traverse<R, COUNT>(sc, o, d, cv, wk);
+      if constexpr (PACKET) {
+        traverse_packet<R, COUNT>(sc, o, d, need_n, cv, wk, lds);
+      } else {
+        traverse<R, COUNT>(sc, o, d, cv, wk, lds);
+      }
       const R other = cv.have ? sc.materials[cv.bflags >> PF_MAT_SHIFT].refractive : R(1);
       const bool h_before = (c_before & 1) != 0;
       if (h_before && (!cv.have || hmt > cv.bt || (hmt == cv.bt && info.shape > cv.bs)))
@@ -605,16 +778,20 @@ __global__ void __launch_bounds__(256) k_shade(DevScene<R> sc, RayPool<R> pool, 
       const R distance = sqrt(dot(lv, lv));
       const V3<R> ldir = {lv.x / distance, lv.y / distance, lv.z / distance};
       AnyVis<R, COUNT> av(sc, over_point, ldir, distance + EPS, wk);
-      traverse<R, COUNT>(sc, over_point, ldir, av, wk);
+      if constexpr (PACKET) {
+        traverse_packet<R, COUNT>(sc, over_point, ldir, valid, av, wk, lds);
+      } else {
+        if (valid) traverse<R, COUNT>(sc, over_point, ldir, av, wk, lds);
+      }
       shadowed = av.found;
     }
     const V3<R> surface = lighting(sc, m, over_point, eyev, normalv, shadowed);
 
     // children
-    bool want_refl = remaining > 0 && reflective != R(0);
+    bool want_refl = valid && remaining > 0 && reflective != R(0);
     bool want_refr = false;
     V3<R> refr_dir = {R(0), R(0), R(0)};
-    if (remaining > 0 && transparency != R(0)) {
+    if (valid && remaining > 0 && transparency != R(0)) {
       const R n_ratio = n1 / n2;
       const R cos_ti = dot(eyev, normalv);
       const R sin2_t = n_ratio * n_ratio * (R(1) - cos_ti * cos_ti);
@@ -644,8 +821,22 @@ __global__ void __launch_bounds__(256) k_shade(DevScene<R> sc, RayPool<R> pool, 
       }
     }
 
-    uint32_t off_r, off_t;
-    const uint32_t base = wave_alloc2(&ctl->gen_count[gen + 1], want_refl, want_refr, off_r, off_t);
+    // child ids: one atomic per block, the four wave totals meet in LDS
+    const unsigned long long m_r = __ballot(want_refl), m_t = __ballot(want_refr);
+    const uint32_t n_r = __popcll(m_r);
+    if ((threadIdx.x & 63u) == 0) s_cnt[wave] = n_r + __popcll(m_t);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t total = 0;
+      for (int w = 0; w < BLOCK / 64; ++w) total += s_cnt[w];
+      s_base = total ? atomicAdd(&ctl->gen_count[gen + 1].v, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = s_base;
+    for (int w = 0; w < BLOCK / 64; ++w)
+      if (w < (int)wave) base += s_cnt[w];
+    const uint32_t off_r = __popcll(m_r & lanes_below()), off_t = n_r + __popcll(m_t & lanes_below());
+    __syncthreads();
     int32_t child_r = -1, child_t = -1;
     if (want_refl) {
       const unsigned long long id = (unsigned long long)child_start + base + off_r;
@@ -654,7 +845,7 @@ __global__ void __launch_bounds__(256) k_shade(DevScene<R> sc, RayPool<R> pool, 
         st3(pool.org + 3ull * id, over_point);
         st3(pool.dir + 3ull * id, reflectv);
       } else {
-        ctl->overflow = 1;
+        ctl->overflow.v = 1;
       }
     }
     if (want_refr) {
@@ -664,13 +855,15 @@ __global__ void __launch_bounds__(256) k_shade(DevScene<R> sc, RayPool<R> pool, 
         st3(pool.org + 3ull * id, under_point);
         st3(pool.dir + 3ull * id, refr_dir);
       } else {
-        ctl->overflow = 1;
+        ctl->overflow.v = 1;
       }
     }
-    st3(pool.color + 3ull * r, surface);
-    st3(pool.mix + 3ull * r, mk<R>(reflective, transparency, rs));
-    pool.child[2ull * r] = child_r;
-    pool.child[2ull * r + 1] = child_t;
+    if (valid) {
+      st3(pool.color + 3ull * r, surface);
+      st3(pool.mix + 3ull * r, mk<R>(reflective, transparency, rs));
+      pool.child[2ull * r] = child_r;
+      pool.child[2ull * r + 1] = child_t;
+    }
   }
   flush_work<COUNT>(ctl, launch, wk);
 }
@@ -682,10 +875,11 @@ template <class R>
 __global__ void __launch_bounds__(256) k_combine(RayPool<R> pool, FrameCtl* ctl, int gen) {
   uint32_t start, gcount;
   gen_range(ctl, gen, pool.capacity, start, gcount);
-  const uint32_t nhit = ctl->hit_count[gen];
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nhit; j += stride) {
-    const uint32_t r = (uint32_t)pool.hitlist[start + j];
+  const uint32_t n_chunks = (gcount + CHUNK - 1) / CHUNK;
+  const uint32_t* chunk_hits = pool.chunk_hits + (size_t)gen * pool.chunks_per_gen;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x)
+  for (uint32_t nhit = chunk_hits[chunk], j = threadIdx.x; j < nhit; j += BLOCK) {
+    const uint32_t r = (uint32_t)pool.hitlist[(size_t)start + (size_t)chunk * CHUNK + j];
     const int32_t cr = pool.child[2ull * r], ct = pool.child[2ull * r + 1];
     if (cr < 0 && ct < 0) continue;  // colour = surface + black + black
     const V3<R> surface = ld3(pool.color + 3ull * r);
@@ -743,13 +937,14 @@ template <class R>
 __global__ void __launch_bounds__(256) k_shadow_points(DevScene<R> sc, const float* pts, uint32_t n, uint8_t* out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  __shared__ int lds_stack[LDS_STACK * BLOCK];
   Work wk;
   const V3<R> p = {R(pts[3 * i]), R(pts[3 * i + 1]), R(pts[3 * i + 2])};
   const V3<R> lv = ld3(sc.light_pos) - p;
   const R distance = sqrt(dot(lv, lv));
   const V3<R> ldir = {lv.x / distance, lv.y / distance, lv.z / distance};
   AnyVis<R, false> av(sc, p, ldir, distance + eps<R>(), wk);
-  traverse<R, false>(sc, p, ldir, av, wk);
+  traverse<R, false>(sc, p, ldir, av, wk, lds_stack + threadIdx.x);
   out[i] = av.found ? 1 : 0;
 }
 

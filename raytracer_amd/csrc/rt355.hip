@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -68,7 +69,8 @@ struct rt355_ctx {
   double pool_factor = 8.0;
   bool counting = false, timing = false;
   int exact_cones = 0;
-  DevBuf org, dir, hit_t, hit_uv, hit_prim, color, mix, child, hitlist, ctl, io_in, io_out, io_out2;
+  int packet_gens = 2;  // generations 0..packet_gens-1 use the wave-packet traversal
+  DevBuf org, dir, hit_t, hit_uv, hit_prim, color, mix, child, hitlist, chunk_hits, ctl, io_in, io_out, io_out2;
   hipEvent_t ev[RT355_MAX_LAUNCH + 1];
   bool ev_ok = false;
   int n_cu = 256;
@@ -158,10 +160,13 @@ int ensure_pool(rt355_ctx* c, uint64_t n_primary, bool secondary, RayPool<R>& po
   if ((rc = c->mix.ensure(cap * 3 * sizeof(R)))) return rc;
   if ((rc = c->child.ensure(cap * 2 * sizeof(int32_t)))) return rc;
   if ((rc = c->hitlist.ensure(cap * sizeof(int32_t)))) return rc;
+  const uint64_t cpg = cap / CHUNK + 2;
+  if ((rc = c->chunk_hits.ensure(cpg * (RT355_MAX_GEN + 1) * sizeof(uint32_t)))) return rc;
   if ((rc = c->ctl.ensure(sizeof(FrameCtl)))) return rc;
   pool.org = (R*)c->org.p, pool.dir = (R*)c->dir.p, pool.hit_t = (R*)c->hit_t.p, pool.hit_uv = (R*)c->hit_uv.p;
   pool.hit_prim = (int32_t*)c->hit_prim.p, pool.color = (R*)c->color.p, pool.mix = (R*)c->mix.p;
   pool.child = (int32_t*)c->child.p, pool.hitlist = (int32_t*)c->hitlist.p;
+  pool.chunk_hits = (uint32_t*)c->chunk_hits.p, pool.chunks_per_gen = (int64_t)cpg;
   pool.capacity = (int64_t)cap;
   return RT355_OK;
 }
@@ -179,11 +184,11 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, uint32
   FrameCtl* ctl = (FrameCtl*)c->ctl.p;
   FrameCtl init;
   memset(&init, 0, sizeof(init));
-  init.gen_count[0] = n_primary;
+  init.gen_count[0].v = n_primary;
   HIP_TRY(hipMemcpyAsync(ctl, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
   const int depth = s->any_secondary ? max_depth : 0;  // no reflective / transparent material: one generation
-  const int block = 256;
-  const uint32_t grid0 = (n_primary + block - 1) / block;
+  const int block = BLOCK;
+  const uint32_t grid0 = (n_primary + CHUNK - 1) / CHUNK;  // one block per chunk of rays
   const uint32_t grid_cap = (uint32_t)c->n_cu * 16;
   auto rec = [&](int kind, int gen) {
     if (c->timing && log.n < RT355_MAX_LAUNCH) HIP_TRY(hipEventRecord(c->ev[log.n], c->stream));
@@ -192,17 +197,24 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, uint32
   };
   for (int g = 0; g <= depth; ++g) {
     // generation g > 0 can hold at most twice the hits of g-1; its size is only known on the device
-    const uint32_t grid = g == 0 ? grid0 : std::min<uint32_t>(grid_cap, (uint32_t)((pool.capacity + block - 1) / block));
+    const uint32_t grid = g == 0 ? grid0 : std::min<uint32_t>(grid_cap, (uint32_t)((pool.capacity + CHUNK - 1) / CHUNK));
     int rc;
     if ((rc = rec(RT355_K_TRACE, g))) return rc;
-    hipLaunchKernelGGL((k_trace<R, COUNT>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, log.n);
+    const bool packet = g < c->packet_gens;
+    if (packet)
+      hipLaunchKernelGGL((k_trace<R, COUNT, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, log.n);
+    else
+      hipLaunchKernelGGL((k_trace<R, COUNT, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, log.n);
     log.n++;
     if ((rc = rec(RT355_K_SHADE, g))) return rc;
-    hipLaunchKernelGGL((k_shade<R, COUNT>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n);
+    if (packet)
+      hipLaunchKernelGGL((k_shade<R, COUNT, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n);
+    else
+      hipLaunchKernelGGL((k_shade<R, COUNT, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n);
     log.n++;
   }
   for (int g = depth - 1; g >= 0; --g) {
-    const uint32_t grid = g == 0 ? grid0 : std::min<uint32_t>(grid_cap, (uint32_t)((pool.capacity + block - 1) / block));
+    const uint32_t grid = g == 0 ? grid0 : std::min<uint32_t>(grid_cap, (uint32_t)((pool.capacity + CHUNK - 1) / CHUNK));
     int rc;
     if ((rc = rec(RT355_K_COMBINE, g))) return rc;
     hipLaunchKernelGGL((k_combine<R>), dim3(grid), dim3(block), 0, c->stream, pool, ctl, g);
@@ -217,14 +229,14 @@ int finish_stats(rt355_ctx* c, const LaunchLog& log, double frame_ms, rt355_stat
   FrameCtl h;
   HIP_TRY(hipMemcpyAsync(&h, c->ctl.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  *overflow = h.overflow != 0;
+  *overflow = h.overflow.v != 0;
   if (!st) return RT355_OK;
   memset(st, 0, sizeof(*st));
   for (int g = 0; g < RT355_MAX_GEN; ++g) {
-    st->radiance_rays[g] = h.gen_count[g];
-    st->hits[g] = h.hit_count[g];
-    st->total_radiance += h.gen_count[g];
-    st->total_shadow += h.hit_count[g];
+    st->radiance_rays[g] = h.gen_count[g].v;
+    st->hits[g] = h.hit_count[g].v;
+    st->total_radiance += h.gen_count[g].v;
+    st->total_shadow += h.hit_count[g].v;
   }
   st->frame_ms = frame_ms;
   st->n_launch = log.n;
@@ -244,9 +256,9 @@ int finish_stats(rt355_ctx* c, const LaunchLog& log, double frame_ms, rt355_stat
       st->launch_prim_tests[i] = prims;
       const int g = log.gen[i];
       if (log.kind[i] == RT355_K_SHADE) {
-        fl += F_SHADE * (double)h.hit_count[g];
+        fl += F_SHADE * (double)h.hit_count[g].v;
         // spawned children of this generation: every ray of generation g+1 (reflect or refract)
-        fl += 0.5 * (F_REFLECT + F_REFRACT) * (double)h.gen_count[g + 1];
+        fl += 0.5 * (F_REFLECT + F_REFRACT) * (double)h.gen_count[g + 1].v;
       }
       st->launch_flops[i] = fl;
     }
@@ -306,9 +318,9 @@ int rays_impl(rt355_ctx* c, const rt355_scene* s, const float* rays_host, size_t
     DevScene<R> sc = dev_scene<R>(s);
     FrameCtl init;
     memset(&init, 0, sizeof(init));
-    init.gen_count[0] = (uint32_t)n;
+    init.gen_count[0].v = (uint32_t)n;
     HIP_TRY(hipMemcpyAsync(c->ctl.p, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL((k_trace<R, false>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (FrameCtl*)c->ctl.p, 0, 0);
+    hipLaunchKernelGGL((k_trace<R, false, false>), dim3((unsigned)((n + CHUNK - 1) / CHUNK)), dim3(block), 0, c->stream, sc, pool, (FrameCtl*)c->ctl.p, 0, 0);
     if ((rc = c->io_out.ensure(n * sizeof(double)))) return rc;
     if ((rc = c->io_out2.ensure(n * sizeof(int32_t)))) return rc;
     hipLaunchKernelGGL((k_export_hits<R>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (uint32_t)n, (double*)c->io_out.p, (int32_t*)c->io_out2.p);
@@ -367,8 +379,9 @@ int upload_impl(rt355_ctx* c, const HostScene& hs, rt355_scene* s) {
   if (any_tri)
     for (size_t i = 0; i < np; ++i) {
       const HostPrim& p = hs.prims[i];
+      tri[i].shape = info[i].shape, tri[i].flags = info[i].flags;
       for (int k = 0; k < 3; ++k) {
-        tri[i].p1[k] = (R)p.p1[k], tri[i].e1[k] = (R)p.e1[k], tri[i].e2[k] = (R)p.e2[k], tri[i].pad[k] = 0;
+        tri[i].p1[k] = (R)p.p1[k], tri[i].e1[k] = (R)p.e1[k], tri[i].e2[k] = (R)p.e2[k];
         trin[i].n1[k] = (R)p.n1[k], trin[i].n2[k] = (R)p.n2[k], trin[i].n3[k] = (R)p.n3[k], trin[i].nf[k] = (R)p.nf[k];
       }
     }
@@ -434,6 +447,7 @@ int rt355_ctx_create(rt355_ctx** out, int device_id, int real_bits) {
       return set_err(RT355_EHIP, "hipEventCreate failed");
     }
   c->ev_ok = true;
+  if (const char* e = getenv("RT355_PACKET_GENS")) c->packet_gens = atoi(e);
   *out = c;
   return RT355_OK;
 }
@@ -442,7 +456,7 @@ void rt355_ctx_destroy(rt355_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (DevBuf* b : {&c->org, &c->dir, &c->hit_t, &c->hit_uv, &c->hit_prim, &c->color, &c->mix, &c->child, &c->hitlist, &c->ctl, &c->io_in, &c->io_out, &c->io_out2}) b->release();
+  for (DevBuf* b : {&c->org, &c->dir, &c->hit_t, &c->hit_uv, &c->hit_prim, &c->color, &c->mix, &c->child, &c->hitlist, &c->chunk_hits, &c->ctl, &c->io_in, &c->io_out, &c->io_out2}) b->release();
   if (c->ev_ok)
     for (int i = 0; i <= RT355_MAX_LAUNCH; ++i) (void)hipEventDestroy(c->ev[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -17,6 +17,12 @@ namespace rt355 {
 constexpr int TILE = 32;             // image tile edge; tile t belongs to rank t % n_ranks
 constexpr int TILE_PIX = TILE * TILE;
 constexpr int STACK_DEPTH = 64;      // traversal stack entries; the builder keeps the tree shallower
+constexpr int LDS_STACK = 24;        // of which this many live in LDS (one column per lane); the rest in scratch
+constexpr int BLOCK = 256;           // threads per block of the traversal kernels
+constexpr int CHUNK_K = 2;           // rays per thread per chunk
+constexpr int CHUNK = BLOCK * CHUNK_K;  // a block compacts its hits / children once per chunk: one atomic per chunk
+constexpr uint32_t LEAF_FIRST_MASK = 0x1FFFFFFu;  // leaf reference ~c: first | tri-only flag << 25 | count << 26
+constexpr uint32_t LEAF_TRI_BIT = 1u << 25;       // every prim of the leaf is a triangle with identity transform
 constexpr int MAX_TREE_DEPTH = 60;
 constexpr int LEAF_MAX = 4;
 constexpr int N_WORK_COUNTERS = 12;  // per launch: [0] box tests, [1] xforms, [2..10) prim tests per kind
@@ -33,9 +39,9 @@ struct PrimInfo {
 };
 
 template <class R>
-struct BvhNode {
+struct alignas(16) BvhNode {
   R lo0[3], hi0[3], lo1[3], hi1[3];
-  int32_t c0, c1;  // >= 0: inner node index; < 0: leaf, ~c = first | (count << 26)
+  int32_t c0, c1;  // >= 0: inner node index; < 0: leaf reference, see LEAF_*
   int32_t pad0, pad1;
 };
 
@@ -56,9 +62,9 @@ struct DevXform {  // rows 0..2 of the inverse transformation (affine): x' = r0 
 };
 
 template <class R>
-struct DevTri {  // Moeller-Trumbore operands, object space (src/triangle.rs:83-84)
+struct alignas(16) DevTri {  // Moeller-Trumbore operands, object space (src/triangle.rs:83-84)
   R p1[3], e1[3], e2[3];
-  R pad[3];
+  int32_t shape, flags;  // copy of prim_info: one fetch per triangle test
 };
 
 template <class R>
@@ -98,17 +104,24 @@ struct RayPool {
   R* color;    // 3 per ray: surface colour, replaced by the combined colour in the combine pass
   R* mix;      // 3 per ray: reflective, transparency, schlick reflectance (< 0: plain sum)
   int32_t* child;      // 2 per ray: reflected, refracted child ray id (-1 = none)
-  int32_t* hitlist;    // per generation region: ids of the rays that hit something
+  int32_t* hitlist;    // ids of the rays that hit something: chunk c of a generation owns the slots
+                       // [gen start + c*CHUNK, +chunk_hits), filled in ray order (no global atomics)
+  uint32_t* chunk_hits;  // [generation][chunk] number of hits of the chunk
+  int64_t chunks_per_gen;
   int64_t capacity;
 };
 
-// Small device-resident control block; read back once per frame.
+// Small device-resident control block; read back once per frame.  Every counter sits on its own 128-byte
+// line: one word saturates at under 100 atomics per microsecond, and reads of a line that is being
+// hammered by atomics wait behind them.
+struct alignas(128) PaddedCounter {
+  uint32_t v;
+  uint32_t pad[31];
+};
 struct FrameCtl {
-  uint32_t gen_start[RT355_MAX_GEN + 1];
-  uint32_t gen_count[RT355_MAX_GEN + 1];
-  uint32_t hit_count[RT355_MAX_GEN + 1];
-  uint32_t overflow;
-  uint32_t pad;
+  PaddedCounter gen_count[RT355_MAX_GEN + 1];
+  PaddedCounter hit_count[RT355_MAX_GEN + 1];
+  PaddedCounter overflow;
   unsigned long long work[RT355_MAX_LAUNCH][N_WORK_COUNTERS];
 };
 

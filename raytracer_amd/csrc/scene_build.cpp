@@ -194,7 +194,9 @@ struct Builder {
   }
 };
 
-int32_t encode_leaf(int first, int count) { return ~(int32_t)((uint32_t)first | ((uint32_t)count << 26)); }
+int32_t encode_leaf(int first, int count, bool tri_only) {
+  return ~(int32_t)((uint32_t)first | (tri_only ? LEAF_TRI_BIT : 0u) | ((uint32_t)count << 26));
+}
 
 }  // namespace
 
@@ -313,7 +315,7 @@ int build_host_scene(const rt355_shape_desc* shapes, size_t n, double pad_rel, i
     snprintf(err, errlen, "too many distinct materials");
     return RT355_EINVAL;
   }
-  if (bounded.size() >= (1u << 26)) {
+  if (bounded.size() >= LEAF_FIRST_MASK) {
     snprintf(err, errlen, "too many shapes");
     return RT355_EINVAL;
   }
@@ -338,9 +340,17 @@ int build_host_scene(const rt355_shape_desc* shapes, size_t n, double pad_rel, i
     out.prims.reserve(nb + unbounded.size());
     for (size_t k = 0; k < nb; ++k) out.prims.push_back(bounded[B.order[k]]);
     // emit device nodes in DFS order; every inner build node becomes one device node
+    auto leaf_ref = [&](int first, int count) -> int32_t {
+      bool tri_only = count > 0;
+      for (int k = first; k < first + count; ++k) {
+        const HostPrim& q = out.prims[k];
+        if ((q.flags & PF_KIND_MASK) < RT355_TRIANGLE || !(q.flags & PF_IDENTITY)) tri_only = false;
+      }
+      return encode_leaf(first, count, tri_only);
+    };
     auto child_ref = [&](int bn, std::vector<int>& map) -> int32_t {
       const BuildNode& c = B.nodes[bn];
-      if (c.left < 0) return encode_leaf(c.first, c.count);
+      if (c.left < 0) return leaf_ref(c.first, c.count);
       return map[bn];
     };
     std::vector<int> map(B.nodes.size(), -1);
@@ -364,8 +374,8 @@ int build_host_scene(const rt355_shape_desc* shapes, size_t n, double pad_rel, i
       HostNode hn;
       for (int k = 0; k < 3; ++k) hn.lo0[k] = B.nodes[root].box.lo[k], hn.hi0[k] = B.nodes[root].box.hi[k];
       empty_box(hn.lo1, hn.hi1);
-      hn.c0 = encode_leaf(B.nodes[root].first, B.nodes[root].count);
-      hn.c1 = encode_leaf(0, 0);
+      hn.c0 = leaf_ref(B.nodes[root].first, B.nodes[root].count);
+      hn.c1 = encode_leaf(0, 0, false);
       out.nodes.push_back(hn);
     } else {
       for (int bn : dfs) {

@@ -1,0 +1,26 @@
+"""Renders a few frames of one scene through the C ABI; the program rocprofv3 wraps for PMC passes."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401,E402
+
+from raytracer_amd import Device, scenes  # noqa: E402
+from raytracer_amd import dist as rd  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--scene", default="north_star")
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--frames", type=int, default=3)
+ap.add_argument("--real", type=int, default=64)
+a = ap.parse_args()
+world, cam = scenes.CONFIGS[a.scene](a.width, a.height)
+dev = Device.get(0, a.real)
+scene = dev.upload(world)
+out = torch.empty(rd.tiles_per_rank(a.width, a.height, 1) * 1024 * 3, dtype=torch.float32, device="cuda")
+for _ in range(a.frames):
+    rd.render_tiles(scene, cam, 5, 0, 1, out)
+torch.cuda.synchronize()
+print("frames done")
