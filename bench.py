@@ -31,7 +31,7 @@ from raytracer_amd import dist as rd  # noqa: E402
 from raytracer_amd._abi import Stats  # noqa: E402
 
 FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 (FMA) x 2.4 GHz
-KIND_NAME = {1: "k_trace", 2: "k_shade", 3: "k_combine"}
+KIND_NAME = {1: "k_trace", 2: "k_shade", 3: "k_combine", 4: "k_container"}
 
 
 def cpu_baseline(world, cam, depth):
@@ -152,6 +152,9 @@ def main():
         rd.render_tiles(scene, cam, args.depth, rank, world_size, local, st)
         dev.set_counting(False)
         flops = np.array(st.launch_flops[: st.n_launch], dtype=np.float64)
+        maxbox = list(st.launch_max_box_tests[: st.n_launch])
+        rays_gen = [int(x) for x in st.radiance_rays]
+        hits_gen = [int(x) for x in st.hits]
         kinds = list(st.launch_kind[: st.n_launch])
         gens = list(st.launch_gen[: st.n_launch])
         k = int(np.argmax(ms_l))
@@ -170,7 +173,8 @@ def main():
             "frame_kernel_ms": round(float(ms_l.sum()), 4),
             "frame_frac": round(float(flops.sum() / (ms_l.sum() * 1e-3) / 1e12 / (FP64_VALU_PEAK_TFLOPS if args.real == 64 else 2 * FP64_VALU_PEAK_TFLOPS)), 5),
             "launches": [{"kernel": KIND_NAME.get(kinds[i], "?"), "gen": gens[i], "ms": round(float(ms_l[i]), 4),
-                          "gflop": round(float(flops[i]) / 1e9, 4)} for i in range(len(kinds))],
+                          "gflop": round(float(flops[i]) / 1e9, 4), "max_box_tests_one_lane": int(maxbox[i]), "max_wave_clocks": int(st.launch_max_wave_clocks[i])} for i in range(len(kinds))],
+            "rays_by_generation": rays_gen, "hits_by_generation": hits_gen,
         }
         if not args.no_cpu_baseline and world_size == 1:
             out["cpu_baseline"] = cpu_baseline(world, cam, args.depth)

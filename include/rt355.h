@@ -97,9 +97,10 @@ typedef struct rt355_camera_desc {
 /* Kernel classes recorded per launch in rt355_stats.launch_kind. */
 enum rt355_launch_kind {
   RT355_K_TRACE = 1,   /* nearest-hit traversal (generation 0 also generates the primary rays) */
-  RT355_K_SHADE = 2,   /* precompute + n1/n2 + shadow ray + Phong + child-ray spawn            */
-  RT355_K_COMBINE = 3, /* child colours folded into their parent, last pass writes the canvas  */
-  RT355_K_CLEAR = 4
+  RT355_K_SHADE = 2,   /* precompute + shadow ray + child-ray spawn (reflect / refract / schlick)   */
+  RT355_K_COMBINE = 3, /* Phong lighting + child colours folded into their parent; generation 0
+                          writes the canvas */
+  RT355_K_CONTAINER = 4 /* n1 / n2 of hits on transparent shapes */
 };
 
 /* Per-frame statistics.  Ray counts are always filled.  Work counters (box_tests ... flops) are
@@ -118,6 +119,8 @@ typedef struct rt355_stats {
   /* counting mode, per launch */
   uint64_t launch_box_tests[RT355_MAX_LAUNCH];  /* child-box slab tests               */
   uint64_t launch_prim_tests[RT355_MAX_LAUNCH]; /* local_intersect calls, all kinds    */
+  uint64_t launch_max_box_tests[RT355_MAX_LAUNCH]; /* most box tests done by one lane */
+  uint64_t launch_max_wave_clocks[RT355_MAX_LAUNCH]; /* k_trace: longest traversal of one wave, shader clocks */
   double launch_flops[RT355_MAX_LAUNCH];        /* algorithmic FLOPs, see rt355_flop_table */
 } rt355_stats;
 

@@ -14,7 +14,7 @@ SPHERE, PLANE, CUBE, CYLINDER, CONE, GROUP, TRIANGLE, SMOOTH_TRIANGLE = range(8)
 # enum rt355_pattern (order of `enum Pattern`, src/pattern.rs:6-12; 0 = None)
 PATTERN_NONE, PATTERN_STRIPE, PATTERN_GRADIENT, PATTERN_RING, PATTERN_CHECKER, PATTERN_TEST = range(6)
 
-K_TRACE, K_SHADE, K_COMBINE, K_CLEAR = 1, 2, 3, 4
+K_TRACE, K_SHADE, K_COMBINE, K_CONTAINER = 1, 2, 3, 4
 
 
 class MaterialDesc(C.Structure):
@@ -71,6 +71,8 @@ class Stats(C.Structure):
         ("launch_ms", C.c_float * RT355_MAX_LAUNCH),
         ("launch_box_tests", C.c_uint64 * RT355_MAX_LAUNCH),
         ("launch_prim_tests", C.c_uint64 * RT355_MAX_LAUNCH),
+        ("launch_max_box_tests", C.c_uint64 * RT355_MAX_LAUNCH),
+        ("launch_max_wave_clocks", C.c_uint64 * RT355_MAX_LAUNCH),
         ("launch_flops", C.c_double * RT355_MAX_LAUNCH),
     ]
 

@@ -6,7 +6,7 @@
 // rays whose `remaining` is max_depth - g) and each generation runs three data-parallel kernels:
 //
 //   k_trace    World::intersect + Intersections::hit        one thread per ray, BVH traversal
-//   k_shade    prepare_computation + is_shadowed + lighting  one thread per HIT, spawns child rays into
+//   k_shade    prepare_computation + is_shadowed + lighting  one thread per ray that hit, spawns child rays into
 //              + reflect / refract / schlick                 generation g+1 (wave64 ballot compaction)
 //   k_combine  shade_hit's final sum                          run from the deepest generation back to 0
 //
@@ -19,6 +19,8 @@
 // templated on the scalar type R (double = graded configuration, float = the reference's precision).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <limits>
 
 #include "rt355_device.h"
 
@@ -74,6 +76,7 @@ struct Work {  // per-thread work counters (counting mode only)
 template <bool COUNT> RT_FN void flush_work(FrameCtl* ctl, int launch, const Work& w) {
   if constexpr (COUNT) {
     if (w.box) atomicAdd(&ctl->work[launch][0], (unsigned long long)w.box);
+    if (w.box) atomicMax(&ctl->work[launch][10], (unsigned long long)w.box);  // longest traversal of one lane
     if (w.xf) atomicAdd(&ctl->work[launch][1], (unsigned long long)w.xf);
     for (int k = 0; k < 8; ++k)
       if (w.prim[k]) atomicAdd(&ctl->work[launch][2 + k], (unsigned long long)w.prim[k]);
@@ -193,17 +196,32 @@ RT_FN void prim_hits(const DevScene<R>& sc, int p, int flags, V3<R> wo, V3<R> wd
 // Moeller-Trumbore on one triangle record (src/shape.rs:328-375); the ray is already in object space.
 // ------------------------------------------------------------------------------------------------
 template <class R>
-RT_FN bool tri_hit(const DevTri<R>& T, V3<R> o, V3<R> d, R& t, R& u, R& v) {
-  const V3<R> e1 = ld3(T.e1), e2 = ld3(T.e2), p1 = ld3(T.p1);
+RT_FN bool tri_hit(const DevTri& T, V3<R> o, V3<R> d, R& t, R& u, R& v) {
+  const V3<R> p1 = {R(T.p1[0]), R(T.p1[1]), R(T.p1[2])};
+  const V3<R> e1 = {R(T.p2[0]) - p1.x, R(T.p2[1]) - p1.y, R(T.p2[2]) - p1.z};  // src/triangle.rs:83
+  const V3<R> e2 = {R(T.p3[0]) - p1.x, R(T.p3[1]) - p1.y, R(T.p3[2]) - p1.z};  // src/triangle.rs:84
   const V3<R> dir_cross_e2 = cross(d, e2);
   const R det = dot(e1, dir_cross_e2);
   if (approx_zero(fabs(det))) return false;
-  const R f = R(1) / det;
   const V3<R> p1_to_origin = o - p1;
-  u = f * dot(p1_to_origin, dir_cross_e2);
-  if (u < R(0) || u > R(1)) return false;
+  // The reference divides first (f = 1/det) and then tests u = f*un, v = f*vn.  Most tests miss, and a
+  // miss can be told without the division: u < 0 exactly when un and det differ in sign, and u > 1
+  // (or u + v > 1) for certain when the numerator exceeds |det| by more than the rounding of the
+  // products.  Whatever is not rejected here goes through the reference's own expressions below.
+  const R adet = fabs(det);
+  const R slack = adet * (R(1) + R(16) * std::numeric_limits<R>::epsilon());
+  const R tiny = adet * (R(16) * std::numeric_limits<R>::min());
+  const R un = dot(p1_to_origin, dir_cross_e2);
+  const R aun = fabs(un);
+  if (aun > tiny && (((un < R(0)) != (det < R(0))) || aun > slack)) return false;
   const V3<R> origin_cross_e1 = cross(p1_to_origin, e1);
-  v = f * dot(d, origin_cross_e1);
+  const R vn = dot(d, origin_cross_e1);
+  const R avn = fabs(vn);
+  if (avn > tiny && (((vn < R(0)) != (det < R(0))) || (aun > tiny && aun + avn > slack))) return false;
+  const R f = R(1) / det;
+  u = f * un;
+  if (u < R(0) || u > R(1)) return false;
+  v = f * vn;
   if (v < R(0) || (u + v) > R(1)) return false;
   t = f * dot(e2, origin_cross_e1);
   return true;
@@ -227,16 +245,16 @@ RT_FN void traverse(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work& wk,
   int cur = 0;
   for (;;) {
     if (cur >= 0) {
-      const BvhNode<R> N = sc.nodes[cur];
+      const BvhNode<float> N = sc.nodes[cur];
       const R tmin = vis.tmin(), tmax = vis.tmax();
-      R ax0 = (N.lo0[0] - o.x) * id.x, ax1 = (N.hi0[0] - o.x) * id.x;
-      R ay0 = (N.lo0[1] - o.y) * id.y, ay1 = (N.hi0[1] - o.y) * id.y;
-      R az0 = (N.lo0[2] - o.z) * id.z, az1 = (N.hi0[2] - o.z) * id.z;
+      R ax0 = (R(N.lo0[0]) - o.x) * id.x, ax1 = (R(N.hi0[0]) - o.x) * id.x;
+      R ay0 = (R(N.lo0[1]) - o.y) * id.y, ay1 = (R(N.hi0[1]) - o.y) * id.y;
+      R az0 = (R(N.lo0[2]) - o.z) * id.z, az1 = (R(N.hi0[2]) - o.z) * id.z;
       R an = fmax(fmax(fmin(ax0, ax1), fmin(ay0, ay1)), fmax(fmin(az0, az1), tmin));
       R af = fmin(fmin(fmax(ax0, ax1), fmax(ay0, ay1)), fmin(fmax(az0, az1), tmax));
-      R bx0 = (N.lo1[0] - o.x) * id.x, bx1 = (N.hi1[0] - o.x) * id.x;
-      R by0 = (N.lo1[1] - o.y) * id.y, by1 = (N.hi1[1] - o.y) * id.y;
-      R bz0 = (N.lo1[2] - o.z) * id.z, bz1 = (N.hi1[2] - o.z) * id.z;
+      R bx0 = (R(N.lo1[0]) - o.x) * id.x, bx1 = (R(N.hi1[0]) - o.x) * id.x;
+      R by0 = (R(N.lo1[1]) - o.y) * id.y, by1 = (R(N.hi1[1]) - o.y) * id.y;
+      R bz0 = (R(N.lo1[2]) - o.z) * id.z, bz1 = (R(N.hi1[2]) - o.z) * id.z;
       R bn = fmax(fmax(fmin(bx0, bx1), fmin(by0, by1)), fmax(fmin(bz0, bz1), tmin));
       R bf = fmin(fmin(fmax(bx0, bx1), fmax(by0, by1)), fmin(fmax(bz0, bz1), tmax));
       const bool ha = an <= af, hb = bn <= bf;
@@ -252,14 +270,25 @@ RT_FN void traverse(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work& wk,
       }
       if (ha) { cur = c0; continue; }
       if (hb) { cur = c1; continue; }
-    } else {
+    } else
+    {
       const uint32_t leaf = (uint32_t)~cur;
       const int first = (int)(leaf & LEAF_FIRST_MASK), count = (int)(leaf >> 26);
       if (leaf & LEAF_TRI_BIT) {
-        for (int k = 0; k < count; ++k) {
-          const DevTri<R> T = sc.tri[first + k];
-          if constexpr (COUNT) wk.prim[T.flags & PF_KIND_MASK]++;
-          if (vis.tri(first + k, T)) return;
+        // all records of the leaf are requested before the first is used: one memory latency per leaf
+        DevTri T[LEAF_MAX];
+#pragma unroll
+        for (int k = 0; k < LEAF_MAX; ++k) T[k] = sc.tri[first + (k < count ? k : 0)];
+#pragma unroll
+        for (int k = 0; k < LEAF_MAX; ++k)
+          if (k < count) {
+            if constexpr (COUNT) wk.prim[T[k].flags & PF_KIND_MASK]++;
+            if (vis.tri(first + k, T[k])) return;
+          }
+        for (int k = LEAF_MAX; k < count; ++k) {  // only leaves forced at the depth limit are larger
+          const DevTri Tk = sc.tri[first + k];
+          if constexpr (COUNT) wk.prim[Tk.flags & PF_KIND_MASK]++;
+          if (vis.tri(first + k, Tk)) return;
         }
       } else {
         for (int k = 0; k < count; ++k)
@@ -285,13 +314,13 @@ RT_FN void traverse(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work& wk,
 template <class T> using cptr = const __attribute__((address_space(4))) T*;
 
 template <class R>
-RT_FN DevTri<R> load_tri_uniform(const DevScene<R>& sc, int p) {
-  DevTri<R> T;
-  cptr<R> q = (cptr<R>)(const R*)&sc.tri[p];
+RT_FN DevTri load_tri_uniform(const DevScene<R>& sc, int p) {
+  DevTri T;
+  cptr<float> q = (cptr<float>)(const float*)&sc.tri[p];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) T.p1[k] = q[k], T.e1[k] = q[3 + k], T.e2[k] = q[6 + k];
+  for (int k = 0; k < 3; ++k) T.p1[k] = q[k], T.p2[k] = q[3 + k], T.p3[k] = q[6 + k];
   cptr<int32_t> qi = (cptr<int32_t>)(const int32_t*)&sc.tri[p].shape;
-  T.shape = qi[0], T.flags = qi[1];
+  T.shape = qi[0], T.flags = qi[1], T.pad = 0;
   return T;
 }
 
@@ -307,19 +336,19 @@ RT_FN void traverse_packet(const DevScene<R>& sc, V3<R> o, V3<R> d, bool live, V
   for (;;) {
     if (__ballot(live) == 0ull) return;
     if (cur >= 0) {
-      cptr<R> q = (cptr<R>)(const R*)&sc.nodes[cur];
+      cptr<float> q = (cptr<float>)(const float*)&sc.nodes[cur];
       cptr<int32_t> qc = (cptr<int32_t>)(const int32_t*)&sc.nodes[cur].c0;
       const int c0 = qc[0], c1 = qc[1];
       const R tmin = vis.tmin(), tmax = vis.tmax();
       // (lo - o) * id == lo * id - o * id up to rounding; boxes are padded by far more than that
-      R ax0 = q[0] * id.x - oid.x, ax1 = q[3] * id.x - oid.x;
-      R ay0 = q[1] * id.y - oid.y, ay1 = q[4] * id.y - oid.y;
-      R az0 = q[2] * id.z - oid.z, az1 = q[5] * id.z - oid.z;
+      R ax0 = R(q[0]) * id.x - oid.x, ax1 = R(q[3]) * id.x - oid.x;
+      R ay0 = R(q[1]) * id.y - oid.y, ay1 = R(q[4]) * id.y - oid.y;
+      R az0 = R(q[2]) * id.z - oid.z, az1 = R(q[5]) * id.z - oid.z;
       R an = fmax(fmax(fmin(ax0, ax1), fmin(ay0, ay1)), fmax(fmin(az0, az1), tmin));
       R af = fmin(fmin(fmax(ax0, ax1), fmax(ay0, ay1)), fmin(fmax(az0, az1), tmax));
-      R bx0 = q[6] * id.x - oid.x, bx1 = q[9] * id.x - oid.x;
-      R by0 = q[7] * id.y - oid.y, by1 = q[10] * id.y - oid.y;
-      R bz0 = q[8] * id.z - oid.z, bz1 = q[11] * id.z - oid.z;
+      R bx0 = R(q[6]) * id.x - oid.x, bx1 = R(q[9]) * id.x - oid.x;
+      R by0 = R(q[7]) * id.y - oid.y, by1 = R(q[10]) * id.y - oid.y;
+      R bz0 = R(q[8]) * id.z - oid.z, bz1 = R(q[11]) * id.z - oid.z;
       R bn = fmax(fmax(fmin(bx0, bx1), fmin(by0, by1)), fmax(fmin(bz0, bz1), tmin));
       R bf = fmin(fmin(fmax(bx0, bx1), fmax(by0, by1)), fmin(fmax(bz0, bz1), tmax));
       const bool ha = live && an <= af, hb = live && bn <= bf;
@@ -338,11 +367,20 @@ RT_FN void traverse_packet(const DevScene<R>& sc, V3<R> o, V3<R> d, bool live, V
       const uint32_t leaf = (uint32_t)~cur;
       const int first = (int)(leaf & LEAF_FIRST_MASK), count = (int)(leaf >> 26);
       if (leaf & LEAF_TRI_BIT) {
-        for (int k = 0; k < count; ++k) {
-          const DevTri<R> T = load_tri_uniform(sc, first + k);
+        DevTri T[LEAF_MAX];
+#pragma unroll
+        for (int k = 0; k < LEAF_MAX; ++k) T[k] = load_tri_uniform(sc, first + (k < count ? k : 0));
+#pragma unroll
+        for (int k = 0; k < LEAF_MAX; ++k)
+          if (k < count && live) {
+            if constexpr (COUNT) wk.prim[T[k].flags & PF_KIND_MASK]++;
+            if (vis.tri(first + k, T[k])) live = false;
+          }
+        for (int k = LEAF_MAX; k < count; ++k) {
+          const DevTri Tk = load_tri_uniform(sc, first + k);
           if (live) {
-            if constexpr (COUNT) wk.prim[T.flags & PF_KIND_MASK]++;
-            if (vis.tri(first + k, T)) live = false;
+            if constexpr (COUNT) wk.prim[Tk.flags & PF_KIND_MASK]++;
+            if (vis.tri(first + k, Tk)) live = false;
           }
         }
       } else {
@@ -363,22 +401,22 @@ struct ClosestVis {
   V3<R> o, d;
   Work& wk;
   R best_t, best_u, best_v;
-  int best_p, best_s;
+  int best_p, best_s, best_flags;
   RT_FN ClosestVis(const DevScene<R>& s, V3<R> o_, V3<R> d_, Work& w)
-      : sc(s), o(o_), d(d_), wk(w), best_t(inf<R>()), best_u(0), best_v(0), best_p(-1), best_s(0x7fffffff) {}
+      : sc(s), o(o_), d(d_), wk(w), best_t(inf<R>()), best_u(0), best_v(0), best_p(-1), best_s(0x7fffffff), best_flags(0) {}
   RT_FN R tmin() const { return R(0); }
   RT_FN R tmax() const { return best_t; }
-  RT_FN void accept(R t, R u, R v, int p, int shape) {
-    if (t >= R(0) && (t < best_t || (t == best_t && shape < best_s))) best_t = t, best_u = u, best_v = v, best_p = p, best_s = shape;
+  RT_FN void accept(R t, R u, R v, int p, int shape, int flags) {
+    if (t >= R(0) && (t < best_t || (t == best_t && shape < best_s))) best_t = t, best_u = u, best_v = v, best_p = p, best_s = shape, best_flags = flags;
   }
   RT_FN bool prim(int p) {
     const PrimInfo info = sc.prim_info[p];
-    prim_hits<R, COUNT>(sc, p, info.flags, o, d, wk, [&](R t, R u, R v, int) { accept(t, u, v, p, info.shape); });
+    prim_hits<R, COUNT>(sc, p, info.flags, o, d, wk, [&](R t, R u, R v, int) { accept(t, u, v, p, info.shape, info.flags); });
     return false;
   }
-  RT_FN bool tri(int p, const DevTri<R>& T) {
+  RT_FN bool tri(int p, const DevTri& T) {
     R t, u, v;
-    if (tri_hit(T, o, d, t, u, v)) accept(t, u, v, p, T.shape);
+    if (tri_hit(T, o, d, t, u, v)) accept(t, u, v, p, T.shape, T.flags);
     return false;
   }
 };
@@ -401,7 +439,7 @@ struct AnyVis {
     });
     return found;
   }
-  RT_FN bool tri(int, const DevTri<R>& T) {
+  RT_FN bool tri(int, const DevTri& T) {
     R t, u, v;
     if (tri_hit(T, o, d, t, u, v) && t >= R(0) && t < limit) found = true;
     return found;
@@ -411,45 +449,44 @@ struct AnyVis {
 // n1/n2 of prepare_computation (src/intersection.rs:86-127) without materialising the sorted list.
 // The reference walks the sorted intersections and toggles shapes in a container: a shape is present
 // after an odd number of its intersections, and the container's last element is the present shape whose
-// latest intersection comes last in the sorted order.  So it is enough to keep, over every OTHER shape
-// with an odd number of intersections sorted before the hit, the one whose latest such intersection has
-// the largest (t, shape index) key.
+// latest intersection comes last in the sorted order.  So the answer is found walking BACKWARDS from the
+// hit: take the intersection with the largest (t, shape index) key below a bound (initially the hit's
+// key); if its shape has an odd number of intersections before the hit it is the container's last
+// element, otherwise lower the bound to that key and look again.  Each step is a nearest-hit query along
+// the reversed ray, culled like any other, instead of a walk over the whole line.
+// The visitor works on the reversed ray (o, -d): its parameter is tr = -t (negating d negates every t
+// exactly), so "largest t below the bound" is "smallest tr above -bound".
 template <class R, bool COUNT>
-struct ContainerVis {
+struct BackwardVis {
   const DevScene<R>& sc;
-  V3<R> o, d;
+  V3<R> o, d;  // d is the REVERSED direction
   Work& wk;
-  R t_hit;
-  int s_hit, p_hit;
+  int p_hit;
+  R bound_t;   // forward t of the bound, exclusive together with bound_s
+  int bound_s;
   bool have;
-  R bt;
-  int bs, bflags;
-  RT_FN ContainerVis(const DevScene<R>& s, V3<R> o_, V3<R> d_, R th, int sh, int ph, Work& w)
-      : sc(s), o(o_), d(d_), wk(w), t_hit(th), s_hit(sh), p_hit(ph), have(false), bt(0), bs(-1), bflags(0) {}
-  RT_FN R tmin() const { return -inf<R>(); }
-  RT_FN R tmax() const { return t_hit; }
-  RT_FN bool before(R t, int shape) const { return t < t_hit || (t == t_hit && shape < s_hit); }
-  RT_FN void present(R mt, int shape, int flags) {
-    if (!have || mt > bt || (mt == bt && shape > bs)) have = true, bt = mt, bs = shape, bflags = flags;
+  R ct;        // forward t of the candidate
+  int cs, cp, cflags;
+  RT_FN BackwardVis(const DevScene<R>& s, V3<R> o_, V3<R> d_, int ph, R bt, int bs, Work& w)
+      : sc(s), o(o_), d(d_), wk(w), p_hit(ph), bound_t(bt), bound_s(bs), have(false), ct(-inf<R>()), cs(-1), cp(-1), cflags(0) {}
+  RT_FN R tmin() const { return -bound_t; }
+  RT_FN R tmax() const { return -ct; }
+  RT_FN void accept(R tr, int p, int shape, int flags) {
+    const R t = -tr;
+    const bool below = t < bound_t || (t == bound_t && shape < bound_s);
+    const bool better = !have || t > ct || (t == ct && shape > cs);
+    if (below && better) have = true, ct = t, cs = shape, cp = p, cflags = flags;  // NaN fails `below`
   }
   RT_FN bool prim(int p) {
     if (p == p_hit) return false;
     const PrimInfo info = sc.prim_info[p];
-    int cnt = 0;
-    R mt = R(0);
-    prim_hits<R, COUNT>(sc, p, info.flags, o, d, wk, [&](R t, R, R, int) {
-      if (before(t, info.shape)) {
-        if (cnt == 0 || t > mt) mt = t;
-        ++cnt;
-      }
-    });
-    if (cnt & 1) present(mt, info.shape, info.flags);
+    prim_hits<R, COUNT>(sc, p, info.flags, o, d, wk, [&](R tr, R, R, int) { accept(tr, p, info.shape, info.flags); });
     return false;
   }
-  RT_FN bool tri(int p, const DevTri<R>& T) {
+  RT_FN bool tri(int p, const DevTri& T) {
     if (p == p_hit) return false;
-    R t, u, v;
-    if (tri_hit(T, o, d, t, u, v) && before(t, T.shape)) present(t, T.shape, T.flags);
+    R tr, u, v;
+    if (tri_hit(T, o, d, tr, u, v)) accept(tr, p, T.shape, T.flags);
     return false;
   }
 };
@@ -461,6 +498,11 @@ struct ContainerVis {
 // than the traversal.
 // ------------------------------------------------------------------------------------------------
 RT_FN unsigned long long lanes_below() { return (1ull << (threadIdx.x & 63u)) - 1ull; }
+RT_FN uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
 
 // Id range of generation `gen`: generations are stacked in the pool in order.  A generation that did
 // not fit is cut at the pool's capacity (the frame is then reported as RT355_ECAPACITY).
@@ -514,74 +556,95 @@ __global__ void __launch_bounds__(256) k_gen_primary(DevCamera<R> cam, RayPool<R
 // k_trace: World::intersect + hit() for every ray of generation `gen`.
 // ------------------------------------------------------------------------------------------------
 template <class R, bool COUNT, bool PACKET>
-__global__ void __launch_bounds__(256) k_trace(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int launch) {
+__global__ void __launch_bounds__(256) k_trace(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch) {
   __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
-  __shared__ uint32_t s_cnt[CHUNK_K * (BLOCK / 64)];
   int* lds = PACKET ? lds_stack + (threadIdx.x >> 6) * STACK_DEPTH : lds_stack + threadIdx.x;
   uint32_t start, count;
   gen_range(ctl, gen, pool.capacity, start, count);
-  const uint32_t n_chunks = (count + CHUNK - 1) / CHUNK;
-  const uint32_t wave = threadIdx.x >> 6;
-  uint32_t* chunk_hits = pool.chunk_hits + (size_t)gen * pool.chunks_per_gen;
+  __shared__ uint32_t s_red[2 * (BLOCK / 64)];
   Work wk;
-  // block-uniform trip counts: every wave reaches the barriers, all 64 lanes stay converged for ballots
-  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-    const uint32_t base = chunk * CHUNK;
-    uint32_t hitbits = 0;
-#pragma unroll 1
-    for (int k = 0; k < CHUNK_K; ++k) {
-      const uint32_t i = base + k * BLOCK + threadIdx.x;
-      const bool valid = i < count;
-      const uint32_t r = start + (valid ? i : 0u);
-      const V3<R> o = ld3(pool.org + 3ull * r), d = ld3(pool.dir + 3ull * r);
-      ClosestVis<R, COUNT> vis(sc, o, d, wk);
-      const bool live = valid && !(d.x == R(0) && d.y == R(0) && d.z == R(0));
-      if constexpr (PACKET) {
-        traverse_packet<R, COUNT>(sc, o, d, live, vis, wk, lds);
-      } else {
-        if (live) traverse<R, COUNT>(sc, o, d, vis, wk, lds);
-      }
-      const bool hit = valid && vis.best_p >= 0;
-      if (valid) {
-        pool.hit_prim[r] = vis.best_p;
-        if (hit) {
-          pool.hit_t[r] = vis.best_t;
-          pool.hit_uv[2ull * r] = vis.best_u;
-          pool.hit_uv[2ull * r + 1] = vis.best_v;
-        } else {
-          st3(pool.color + 3ull * r, mk<R>(R(0), R(0), R(0)));  // world.rs:61-63: a miss is black
-        }
-      }
-      hitbits |= (hit ? 1u : 0u) << k;
+  // one ray per lane per trip; the trip count is block-uniform, so all 64 lanes stay converged for the
+  // ballots of the packet traversal
+  for (uint32_t base = blockIdx.x * BLOCK; base < count; base += gridDim.x * BLOCK) {
+    const uint32_t i = base + threadIdx.x;
+    const bool valid = i < count;
+    const uint32_t r = start + (valid ? i : 0u);
+    const V3<R> o = ld3(pool.org + 3ull * r), d = ld3(pool.dir + 3ull * r);
+    ClosestVis<R, COUNT> vis(sc, o, d, wk);
+    const bool live = valid && !(d.x == R(0) && d.y == R(0) && d.z == R(0));
+    long long t_start = 0;
+    if constexpr (COUNT) t_start = clock64();
+    if constexpr (PACKET) {
+      traverse_packet<R, COUNT>(sc, o, d, live, vis, wk, lds);
+    } else {
+      if (live) traverse<R, COUNT>(sc, o, d, vis, wk, lds);
     }
-    // hits of the chunk, in ray order, into the chunk's own hitlist slots
-    unsigned long long masks[CHUNK_K];
-#pragma unroll
-    for (int k = 0; k < CHUNK_K; ++k) {
-      masks[k] = __ballot((hitbits >> k) & 1u);
-      if ((threadIdx.x & 63u) == 0) s_cnt[k * (BLOCK / 64) + wave] = __popcll(masks[k]);
+    if constexpr (COUNT) {
+      // longest traversal of one wave, in shader clocks (all lanes reconverge here)
+      const unsigned long long dt = (unsigned long long)(clock64() - t_start);
+      if ((threadIdx.x & 63u) == 0) atomicMax(&ctl->work[launch][11], dt);
     }
+    uint32_t n_child = 0;
+    const bool hit = valid && vis.best_p >= 0;
+    if (valid) {
+      pool.hit_prim[r] = vis.best_p;
+      if (hit) {
+        pool.hit_t[r] = vis.best_t;
+        pool.hit_uv[2ull * r] = vis.best_u;
+        pool.hit_uv[2ull * r + 1] = vis.best_v;
+        if (remaining > 0) n_child = ((vis.best_flags & PF_REFLECTIVE) ? 1u : 0u) + ((vis.best_flags & PF_TRANSPARENT) ? 1u : 0u);
+      }
+    }
+    // per block of rays: hits (= shadow rays) and the upper bound of child rays, for k_scan
+    const uint32_t wh = __popcll(__ballot(hit)), wc = wave_sum(n_child);
+    if ((threadIdx.x & 63u) == 0) s_red[threadIdx.x >> 6] = wh, s_red[BLOCK / 64 + (threadIdx.x >> 6)] = wc;
     __syncthreads();
-    uint32_t total = 0;
-#pragma unroll
-    for (int k = 0; k < CHUNK_K; ++k) {
-      uint32_t before = total;
-#pragma unroll
-      for (int w = 0; w < BLOCK / 64; ++w) {
-        const uint32_t c = s_cnt[k * (BLOCK / 64) + w];
-        if (w < (int)wave) before += c;
-        total += c;
-      }
-      if ((hitbits >> k) & 1u)
-        pool.hitlist[(size_t)start + base + before + __popcll(masks[k] & lanes_below())] = (int32_t)(start + base + k * BLOCK + threadIdx.x);
-    }
     if (threadIdx.x == 0) {
-      chunk_hits[chunk] = total;
-      if (total) atomicAdd(&ctl->hit_count[gen].v, total);
+      uint32_t th = 0, tc = 0;
+      for (int w = 0; w < BLOCK / 64; ++w) th += s_red[w], tc += s_red[BLOCK / 64 + w];
+      pool.blk_hits[base / BLOCK] = th;
+      pool.blk_children[base / BLOCK] = tc;
     }
     __syncthreads();
   }
   flush_work<COUNT>(ctl, launch, wk);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_scan: exclusive prefix of the per-block child bounds of generation `gen` (one block, no atomics),
+// plus the generation's hit total and the size of generation gen+1.  Child-ray ids become a pure
+// function of the ray order, so a frame always lays its rays out the same way.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_scan(const uint32_t* blk_hits, const uint32_t* blk_children, uint32_t* blk_base, FrameCtl* ctl, int gen, long long capacity) {
+  __shared__ uint32_t s_c[1024], s_h[1024];
+  uint32_t start, count;
+  gen_range(ctl, gen, capacity, start, count);
+  const uint32_t n = (count + BLOCK - 1) / BLOCK;
+  const uint32_t per = (n + 1023u) / 1024u;
+  const uint32_t lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+  uint32_t c = 0, h = 0;
+  for (uint32_t k = lo; k < hi; ++k) c += blk_children[k], h += blk_hits[k];
+  s_c[threadIdx.x] = c, s_h[threadIdx.x] = h;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    uint32_t vc = 0, vh = 0;
+    if ((int)threadIdx.x >= off) vc = s_c[threadIdx.x - off], vh = s_h[threadIdx.x - off];
+    __syncthreads();
+    s_c[threadIdx.x] += vc, s_h[threadIdx.x] += vh;
+    __syncthreads();
+  }
+  uint32_t run = s_c[threadIdx.x] - c;
+  for (uint32_t k = lo; k < hi; ++k) {
+    blk_base[k] = run;
+    run += blk_children[k];
+  }
+  if (threadIdx.x == 1023) {
+    ctl->hit_count[gen].v = s_h[1023];
+    unsigned long long total = s_c[1023];
+    const unsigned long long room = (unsigned long long)capacity - ((unsigned long long)start + count);
+    if (total > room) total = room, ctl->overflow.v = 1;
+    ctl->gen_count[gen + 1].v = (uint32_t)total;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -681,103 +744,165 @@ RT_FN V3<R> lighting(const DevScene<R>& sc, const DevMaterial<R>& m, V3<R> point
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_shade: one thread per hit of generation `gen`.
-//   prepare_computation (src/intersection.rs:60-142), is_shadowed (src/world.rs:45-57), lighting,
-//   reflected_color / refracted_color ray set-up (src/world.rs:68-102), schlick (src/computation.rs:20-33).
+// The part of prepare_computation (src/intersection.rs:60-85) that needs no intersection list.  It is
+// evaluated from the ray and hit records wherever it is needed (k_shade twice, k_combine once) instead of
+// being carried in registers or in memory: a few dozen flops against a dozen live doubles.
+// ------------------------------------------------------------------------------------------------
+template <class R>
+struct Prepared {
+  V3<R> d, eyev, normalv, normalv_temp, over_point, under_point;
+};
+template <class R>
+RT_FN Prepared<R> prepare(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t r, int p, int flags) {
+  Prepared<R> c;
+  const V3<R> o = ld3(pool.org + 3ull * r);
+  c.d = ld3(pool.dir + 3ull * r);
+  const R t = pool.hit_t[r];
+  R u = R(0), v = R(0);
+  if ((flags & PF_KIND_MASK) == RT355_SMOOTH_TRIANGLE) u = pool.hit_uv[2ull * r], v = pool.hit_uv[2ull * r + 1];
+  const V3<R> point = o + c.d * t;  // src/ray.rs:22-24
+  c.eyev = R(-1) * c.d;
+  c.normalv_temp = normal_at(sc, p, flags, point, u, v);
+  const bool inside = dot(c.normalv_temp, c.eyev) < R(0);
+  c.normalv = inside ? R(-1) * c.normalv_temp : R(1) * c.normalv_temp;
+  const V3<R> offset = eps<R>() * c.normalv;
+  c.over_point = point + offset;
+  c.under_point = point - offset;
+  return c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_container: n1 / n2 of prepare_computation (src/intersection.rs:86-127) for the hits of generation
+// `gen` on transparent shapes.  Launched only for scenes with a transparent material and only while
+// rays can still be spawned: n1 / n2 feed refracted_color and schlick, which multiply black otherwise.
+// ------------------------------------------------------------------------------------------------
+template <class R, bool COUNT, bool PACKET>
+__global__ void __launch_bounds__(256) k_container(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int launch) {
+  uint32_t start, gcount;
+  gen_range(ctl, gen, pool.capacity, start, gcount);
+  __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
+  int* lds = PACKET ? lds_stack + (threadIdx.x >> 6) * STACK_DEPTH : lds_stack + threadIdx.x;
+  Work wk;
+  for (uint32_t rbase = blockIdx.x * BLOCK; rbase < gcount; rbase += gridDim.x * BLOCK) {
+    const uint32_t i = rbase + threadIdx.x;
+    const uint32_t r = start + (i < gcount ? i : 0u);
+    const int p_raw = pool.hit_prim[r];
+    const int p = (i < gcount && p_raw >= 0) ? p_raw : 0;
+    const PrimInfo info = sc.prim_info[p];
+    const bool need = i < gcount && p_raw >= 0 && (info.flags & PF_TRANSPARENT);
+    if (__ballot(need) == 0ull) continue;  // wave-uniform
+    const V3<R> o = ld3(pool.org + 3ull * r), d = ld3(pool.dir + 3ull * r);
+    const R t = need ? pool.hit_t[r] : R(1);
+    // the hit shape's own intersections, emission order
+    R h0 = R(0), h1 = R(0), h2 = R(0), h3 = R(0);
+    int nh = 0;
+    if (need)
+      prim_hits<R, COUNT>(sc, p, info.flags, o, d, wk, [&](R tt, R, R, int em) {
+        if (em == 0) h0 = tt; else if (em == 1) h1 = tt; else if (em == 2) h2 = tt; else if (em == 3) h3 = tt;
+        nh = em + 1;
+      });
+    const R ht[4] = {h0, h1, h2, h3};
+    // the entry the reference treats as "the hit" last: same t, latest emission
+    int m_last = 0;
+    R best = inf<R>();
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < nh) {
+        const R dd = fabs(ht[k] - t);
+        if (dd <= best) best = dd, m_last = k;
+      }
+    R tm = t;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (nh && k == m_last) tm = ht[k];
+    int c_before = 0;
+    R hmt = R(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < nh && (ht[k] < tm || (ht[k] == tm && k < m_last))) {
+        if (c_before == 0 || ht[k] >= hmt) hmt = ht[k];
+        ++c_before;
+      }
+    // the container's last element among the OTHER shapes: walk backwards from the hit
+    const V3<R> rd = R(-1) * d;
+    bool searching = need, found = false;
+    int other_flags = 0, other_s = -1;
+    R other_t = R(0);
+    R bound_t = t;
+    int bound_s = info.shape;
+    for (int step = 0; step < 4096; ++step) {
+      if (PACKET ? (__ballot(searching) == 0ull) : !searching) break;
+      BackwardVis<R, COUNT> bv(sc, o, rd, p, bound_t, bound_s, wk);
+      if constexpr (PACKET) {
+        traverse_packet<R, COUNT>(sc, o, rd, searching, bv, wk, lds);
+      } else {
+        if (searching) traverse<R, COUNT>(sc, o, rd, bv, wk, lds);
+      }
+      if (searching) {
+        if (!bv.have) {
+          searching = false;
+        } else {
+          // is that shape present, i.e. does it have an odd number of intersections before the hit?
+          int cnt = 0;
+          prim_hits<R, COUNT>(sc, bv.cp, bv.cflags, o, d, wk, [&](R tt, R, R, int) {
+            if (tt < t || (tt == t && bv.cs < info.shape)) ++cnt;
+          });
+          if (cnt & 1) {
+            found = true, other_flags = bv.cflags, other_s = bv.cs, other_t = bv.ct;
+            searching = false;
+          } else {
+            bound_t = bv.ct, bound_s = bv.cs;
+          }
+        }
+      }
+    }
+    if (need) {
+      const R own = sc.materials[info.flags >> PF_MAT_SHIFT].refractive;
+      const R other = found ? sc.materials[other_flags >> PF_MAT_SHIFT].refractive : R(1);
+      const bool h_before = (c_before & 1) != 0;
+      const bool own_last = h_before && (!found || hmt > other_t || (hmt == other_t && info.shape > other_s));
+      pool.n12[2ull * r] = own_last ? own : other;                  // n1
+      pool.n12[2ull * r + 1] = ((c_before + 1) & 1) ? own : other;  // n2
+    }
+  }
+  flush_work<COUNT>(ctl, launch, wk);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_shade: is_shadowed (src/world.rs:45-57) for every hit of generation `gen`, then the set-up of its
+// reflected / refracted rays (src/world.rs:68-102) and the Schlick reflectance (src/computation.rs:20-33).
+// One thread per ray; lanes whose ray missed idle.  Primary and mirror rays hit or miss in large screen
+// regions, so most waves are (nearly) full or skipped outright.
 // ------------------------------------------------------------------------------------------------
 template <class R, bool COUNT, bool PACKET>
 __global__ void __launch_bounds__(256) k_shade(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch) {
   uint32_t start, gcount;
   gen_range(ctl, gen, pool.capacity, start, gcount);
-  const uint32_t n_chunks = (gcount + CHUNK - 1) / CHUNK;
   const uint32_t child_start = start + gcount;
   const uint32_t wave = threadIdx.x >> 6;
-  const R EPS = eps<R>();
   __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
   __shared__ uint32_t s_cnt[BLOCK / 64];
-  __shared__ uint32_t s_base;
   int* lds = PACKET ? lds_stack + (threadIdx.x >> 6) * STACK_DEPTH : lds_stack + threadIdx.x;
-  const uint32_t* chunk_hits = pool.chunk_hits + (size_t)gen * pool.chunks_per_gen;
   Work wk;
-  // block-uniform trip counts: every wave reaches the barriers, all 64 lanes stay converged for ballots
-  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x)
-  for (uint32_t nhit = chunk_hits[chunk], j0 = 0; j0 < nhit; j0 += BLOCK) {
-    const uint32_t j = j0 + threadIdx.x;
-    const bool valid = j < nhit;
-    const uint32_t r = (uint32_t)pool.hitlist[(size_t)start + (size_t)chunk * CHUNK + (valid ? j : 0u)];
-    const V3<R> o = ld3(pool.org + 3ull * r), d = ld3(pool.dir + 3ull * r);
-    const R t = pool.hit_t[r];
-    const int p = pool.hit_prim[r];
+  // block-uniform trip count: every wave reaches the barriers, all 64 lanes stay converged for ballots
+  for (uint32_t rbase = blockIdx.x * BLOCK; rbase < gcount; rbase += gridDim.x * BLOCK) {
+    const uint32_t i = rbase + threadIdx.x;
+    const uint32_t r = start + (i < gcount ? i : 0u);
+    const int p_raw = pool.hit_prim[r];
+    const bool valid = i < gcount && p_raw >= 0;
+    if (__syncthreads_or(valid) == 0) continue;  // block-uniform
+    const int p = valid ? p_raw : 0;
     const PrimInfo info = sc.prim_info[p];
-    const DevMaterial<R>& m = sc.materials[info.flags >> PF_MAT_SHIFT];
-    const int kind = info.flags & PF_KIND_MASK;
-    R u = R(0), v = R(0);
-    if (kind == RT355_SMOOTH_TRIANGLE) u = pool.hit_uv[2ull * r], v = pool.hit_uv[2ull * r + 1];
-
-    const V3<R> point = o + d * t;  // src/ray.rs:22-24
-    const V3<R> eyev = R(-1) * d;
-    const V3<R> normalv_temp = normal_at(sc, p, info.flags, point, u, v);
-    const bool inside = dot(normalv_temp, eyev) < R(0);
-    const V3<R> normalv = inside ? R(-1) * normalv_temp : R(1) * normalv_temp;
-    const V3<R> offset = EPS * normalv;
-    const V3<R> over_point = point + offset, under_point = point - offset;
-    const V3<R> reflectv = reflect(d, normalv_temp);  // un-flipped normal (src/intersection.rs:85)
-
-    const R reflective = m.reflective, transparency = m.transparency;
-    R n1 = R(1), n2 = R(1);
-    const bool need_n = valid && transparency != R(0);
-    if (PACKET ? (__ballot(need_n) != 0ull) : need_n) {
-      // the hit shape's own intersections, emission order
-      R ht[4] = {R(0), R(0), R(0), R(0)};
-      int nh = 0;
-      if (need_n)
-        prim_hits<R, COUNT>(sc, p, info.flags, o, d, wk, [&](R tt, R, R, int em) {
-          if (em == 0) ht[0] = tt; else if (em == 1) ht[1] = tt; else if (em == 2) ht[2] = tt; else if (em == 3) ht[3] = tt;
-          nh = em + 1;
-        });
-      // the entry the reference treats as "the hit" last: same t, latest emission
-      int m_last = 0;
-      R best = inf<R>();
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (k < nh) {
-          const R dd = fabs(ht[k] - t);
-          if (dd <= best) best = dd, m_last = k;
-        }
-      R tm = t;
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (nh && k == m_last) tm = ht[k];
-      int c_before = 0;
-      R hmt = R(0);
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (k < nh && (ht[k] < tm || (ht[k] == tm && k < m_last))) {
-          if (c_before == 0 || ht[k] >= hmt) hmt = ht[k];
-          ++c_before;
-        }
-      ContainerVis<R, COUNT> cv(sc, o, d, t, info.shape, p, wk);
-      if constexpr (PACKET) {
-        traverse_packet<R, COUNT>(sc, o, d, need_n, cv, wk, lds);
-      } else {
-        traverse<R, COUNT>(sc, o, d, cv, wk, lds);
-      }
-      const R other = cv.have ? sc.materials[cv.bflags >> PF_MAT_SHIFT].refractive : R(1);
-      const bool h_before = (c_before & 1) != 0;
-      if (h_before && (!cv.have || hmt > cv.bt || (hmt == cv.bt && info.shape > cv.bs)))
-        n1 = m.refractive;
-      else
-        n1 = other;
-      n2 = ((c_before + 1) & 1) ? m.refractive : other;
-    }
 
     // is_shadowed(over_point)
     bool shadowed;
     {
+      V3<R> over_point = {R(0), R(0), R(0)};
+      if (valid) over_point = prepare(sc, pool, r, p, info.flags).over_point;
       const V3<R> lv = ld3(sc.light_pos) - over_point;
       const R distance = sqrt(dot(lv, lv));
       const V3<R> ldir = {lv.x / distance, lv.y / distance, lv.z / distance};
-      AnyVis<R, COUNT> av(sc, over_point, ldir, distance + EPS, wk);
+      AnyVis<R, COUNT> av(sc, over_point, ldir, distance + eps<R>(), wk);
       if constexpr (PACKET) {
         traverse_packet<R, COUNT>(sc, over_point, ldir, valid, av, wk, lds);
       } else {
@@ -785,125 +910,107 @@ __global__ void __launch_bounds__(256) k_shade(DevScene<R> sc, RayPool<R> pool, 
       }
       shadowed = av.found;
     }
-    const V3<R> surface = lighting(sc, m, over_point, eyev, normalv, shadowed);
 
-    // children
-    bool want_refl = valid && remaining > 0 && reflective != R(0);
+    // children.  The ray id goes through an opaque move so that nothing of the first prepare() is kept
+    // alive in registers across the traversal.
+    uint32_t r2 = r;
+    asm volatile("" : "+v"(r2));
+    const bool slot_r = valid && remaining > 0 && (info.flags & PF_REFLECTIVE);
+    const bool slot_t = valid && remaining > 0 && (info.flags & PF_TRANSPARENT);
     bool want_refr = false;
-    V3<R> refr_dir = {R(0), R(0), R(0)};
-    if (valid && remaining > 0 && transparency != R(0)) {
-      const R n_ratio = n1 / n2;
-      const R cos_ti = dot(eyev, normalv);
-      const R sin2_t = n_ratio * n_ratio * (R(1) - cos_ti * cos_ti);
-      if (!(sin2_t > R(1))) {
-        const R cos_t = sqrt(R(1) - sin2_t);
-        refr_dir = (n_ratio * cos_ti - cos_t) * normalv - n_ratio * eyev;
-        want_refr = true;
-      }
-    }
+    V3<R> refl_o = {R(0), R(0), R(0)}, refl_d = refl_o, refr_o = refl_o, refr_d = refl_o;
     R rs = R(-1);
-    if (reflective > R(0) && transparency > R(0)) {
-      R cs = dot(eyev, normalv);
-      bool tir = false;
-      if (n1 > n2) {
-        const R n = n1 / n2;
-        const R sin2_t = n * n * (R(1) - cs * cs);
-        if (sin2_t > R(1)) tir = true;
-        else cs = sqrt(R(1) - sin2_t);
-      }
-      if (tir) {
-        rs = R(1);
-      } else {
-        R r0 = (n1 - n2) / (n1 + n2);
-        r0 = r0 * r0;
-        const R k = R(1) - cs;
-        rs = r0 + ((R(1) - r0) * (k * k * k * k * k));
+    if (slot_r || slot_t) {
+      const Prepared<R> c = prepare(sc, pool, r2, p, info.flags);
+      refl_o = c.over_point;
+      refl_d = reflect(c.d, c.normalv_temp);  // un-flipped normal (src/intersection.rs:85)
+      if (slot_t) {
+        const R n1 = pool.n12[2ull * r2], n2 = pool.n12[2ull * r2 + 1];
+        const R n_ratio = n1 / n2;
+        const R cos_ti = dot(c.eyev, c.normalv);
+        const R sin2_t = n_ratio * n_ratio * (R(1) - cos_ti * cos_ti);
+        if (!(sin2_t > R(1))) {
+          const R cos_t = sqrt(R(1) - sin2_t);
+          refr_o = c.under_point;
+          refr_d = (n_ratio * cos_ti - cos_t) * c.normalv - n_ratio * c.eyev;
+          want_refr = true;
+        }
+        if (slot_r) {  // reflective > 0 && transparency > 0 (materials are non-negative): schlick()
+          R cs = cos_ti;
+          bool tir = false;
+          if (n1 > n2) {
+            const R n = n1 / n2;
+            const R s2 = n * n * (R(1) - cs * cs);
+            if (s2 > R(1)) tir = true;
+            else cs = sqrt(R(1) - s2);
+          }
+          if (tir) {
+            rs = R(1);
+          } else {
+            R r0 = (n1 - n2) / (n1 + n2);
+            r0 = r0 * r0;
+            const R k = R(1) - cs;
+            rs = r0 + ((R(1) - r0) * (k * k * k * k * k));
+          }
+        }
       }
     }
 
-    // child ids: one atomic per block, the four wave totals meet in LDS
-    const unsigned long long m_r = __ballot(want_refl), m_t = __ballot(want_refr);
+    // child ids: this block's prefix from k_scan + rank inside the block; the bound counts a refracted
+    // ray for every transparent hit, so a hit that turns out to be total internal reflection leaves
+    // its slot empty (zero direction = no ray).
+    const unsigned long long m_r = __ballot(slot_r), m_t = __ballot(slot_t);
     const uint32_t n_r = __popcll(m_r);
     if ((threadIdx.x & 63u) == 0) s_cnt[wave] = n_r + __popcll(m_t);
     __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t total = 0;
-      for (int w = 0; w < BLOCK / 64; ++w) total += s_cnt[w];
-      s_base = total ? atomicAdd(&ctl->gen_count[gen + 1].v, total) : 0u;
-    }
-    __syncthreads();
-    uint32_t base = s_base;
+    uint32_t base = pool.blk_base[rbase / BLOCK];
     for (int w = 0; w < BLOCK / 64; ++w)
       if (w < (int)wave) base += s_cnt[w];
     const uint32_t off_r = __popcll(m_r & lanes_below()), off_t = n_r + __popcll(m_t & lanes_below());
     __syncthreads();
+    const uint32_t n_holes = __popcll(__ballot(slot_t && !want_refr));
+    if ((threadIdx.x & 63u) == 0 && n_holes) atomicAdd(&ctl->holes[gen + 1].v, n_holes);
+
     int32_t child_r = -1, child_t = -1;
-    if (want_refl) {
+    if (slot_r) {
       const unsigned long long id = (unsigned long long)child_start + base + off_r;
       if (id < (unsigned long long)pool.capacity) {
         child_r = (int32_t)id;
-        st3(pool.org + 3ull * id, over_point);
-        st3(pool.dir + 3ull * id, reflectv);
+        st3(pool.org + 3ull * id, refl_o);
+        st3(pool.dir + 3ull * id, refl_d);
       } else {
         ctl->overflow.v = 1;
       }
     }
-    if (want_refr) {
+    if (slot_t) {
       const unsigned long long id = (unsigned long long)child_start + base + off_t;
       if (id < (unsigned long long)pool.capacity) {
-        child_t = (int32_t)id;
-        st3(pool.org + 3ull * id, under_point);
-        st3(pool.dir + 3ull * id, refr_dir);
+        if (want_refr) child_t = (int32_t)id;
+        st3(pool.org + 3ull * id, refr_o);
+        st3(pool.dir + 3ull * id, refr_d);  // zero when there is no refracted ray
       } else {
         ctl->overflow.v = 1;
       }
     }
     if (valid) {
-      st3(pool.color + 3ull * r, surface);
-      st3(pool.mix + 3ull * r, mk<R>(reflective, transparency, rs));
       pool.child[2ull * r] = child_r;
       pool.child[2ull * r + 1] = child_t;
+      pool.mixr[r] = rs;
+      pool.shadow[r] = shadowed ? 1 : 0;
     }
   }
   flush_work<COUNT>(ctl, launch, wk);
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_combine: shade_hit's sum (src/world.rs:117-126) for every hit of generation `gen`, deepest first.
+// k_combine: Material::lighting (src/material.rs:108-162) and shade_hit's sum (src/world.rs:117-126) for
+// every hit of generation `gen`; runs from the deepest generation back to 0, so the children's colours
+// are final when their parent adds them.  Generation 0 may write the canvas directly.
 // ------------------------------------------------------------------------------------------------
-template <class R>
-__global__ void __launch_bounds__(256) k_combine(RayPool<R> pool, FrameCtl* ctl, int gen) {
-  uint32_t start, gcount;
-  gen_range(ctl, gen, pool.capacity, start, gcount);
-  const uint32_t n_chunks = (gcount + CHUNK - 1) / CHUNK;
-  const uint32_t* chunk_hits = pool.chunk_hits + (size_t)gen * pool.chunks_per_gen;
-  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x)
-  for (uint32_t nhit = chunk_hits[chunk], j = threadIdx.x; j < nhit; j += BLOCK) {
-    const uint32_t r = (uint32_t)pool.hitlist[(size_t)start + (size_t)chunk * CHUNK + j];
-    const int32_t cr = pool.child[2ull * r], ct = pool.child[2ull * r + 1];
-    if (cr < 0 && ct < 0) continue;  // colour = surface + black + black
-    const V3<R> surface = ld3(pool.color + 3ull * r);
-    const V3<R> mix = ld3(pool.mix + 3ull * r);
-    V3<R> refl = {R(0), R(0), R(0)}, refr = {R(0), R(0), R(0)};
-    if (cr >= 0) refl = ld3(pool.color + 3ull * cr) * mix.x;
-    if (ct >= 0) refr = ld3(pool.color + 3ull * ct) * mix.y;
-    V3<R> c;
-    if (mix.z >= R(0) || mix.z != mix.z)
-      c = surface + refl * mix.z + refr * (R(1) - mix.z);
-    else
-      c = surface + refr + refl;
-    st3(pool.color + 3ull * r, c);
-  }
-}
+enum OutMode { OUT_NONE = -1, OUT_LINEAR = 0, OUT_ROWMAJOR = 1, OUT_TILES = 2 };
 
-enum OutMode { OUT_LINEAR = 0, OUT_ROWMAJOR = 1, OUT_TILES = 2 };
-
-// Generation-0 colours -> float canvas (Canvas.pixels, src/canvas.rs:8-12).
 template <class R>
-__global__ void __launch_bounds__(256) k_write_canvas(RayPool<R> pool, DevCamera<R> cam, uint32_t n, int mode, float* out) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const V3<R> c = ld3(pool.color + 3ull * i);
+RT_FN void write_pixel(const DevCamera<R>& cam, uint32_t i, int mode, float* out, V3<R> c) {
   size_t o;
   if (mode == OUT_LINEAR) {
     o = (size_t)i * 3;
@@ -919,6 +1026,36 @@ __global__ void __launch_bounds__(256) k_write_canvas(RayPool<R> pool, DevCamera
   }
   out[o] = (float)c.x, out[o + 1] = (float)c.y, out[o + 2] = (float)c.z;
 }
+
+template <class R>
+__global__ void __launch_bounds__(256) k_combine(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, DevCamera<R> cam, int mode, float* out) {
+  uint32_t start, gcount;
+  gen_range(ctl, gen, pool.capacity, start, gcount);
+  for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < gcount; i += gridDim.x * BLOCK) {
+    const uint32_t r = start + i;
+    const int p = pool.hit_prim[r];
+    V3<R> c = {R(0), R(0), R(0)};  // world.rs:61-63: a miss is black
+    if (p >= 0) {
+      const PrimInfo info = sc.prim_info[p];
+      const DevMaterial<R>& m = sc.materials[info.flags >> PF_MAT_SHIFT];
+      const Prepared<R> pc = prepare(sc, pool, r, p, info.flags);
+      const V3<R> surface = lighting(sc, m, pc.over_point, pc.eyev, pc.normalv, pool.shadow[r] != 0);
+      const int32_t cr = pool.child[2ull * r], ct = pool.child[2ull * r + 1];
+      const R rs = pool.mixr[r];
+      V3<R> refl = {R(0), R(0), R(0)}, refr = {R(0), R(0), R(0)};
+      if (cr >= 0) refl = ld3(pool.color + 3ull * cr) * m.reflective;
+      if (ct >= 0) refr = ld3(pool.color + 3ull * ct) * m.transparency;
+      if (rs >= R(0) || rs != rs)
+        c = surface + refl * rs + refr * (R(1) - rs);
+      else
+        c = surface + refr + refl;
+    }
+    if (gen > 0 || mode == OUT_NONE) st3(pool.color + 3ull * r, c);
+    if (gen == 0 && mode != OUT_NONE) write_pixel(cam, i, mode, out, c);
+  }
+}
+
+
 
 // rank buffers (tile-major) -> row-major canvas, after the gather on rank 0
 __global__ void __launch_bounds__(256) k_untile(const float* gathered, float* out, int width, int height, int tiles_x, int n_tiles, int n_ranks, long long tiles_per_rank) {

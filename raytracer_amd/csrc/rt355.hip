@@ -37,7 +37,7 @@ int set_err(int code, const std::string& msg) {
 // FLOP weights per unit of work: 1 per add/sub/mul/div/sqrt/min/max/compare, FMA = 2.
 const double F_PRIMARY = 40, F_BOX = 24, F_XFORM = 33;
 const double F_KIND[8] = {28 /*sphere*/, 4 /*plane*/, 20 /*cube*/, 50 /*cylinder*/, 62 /*cone*/, 0, 52 /*triangle*/, 52 /*smooth*/};
-const double F_SHADE = 190, F_REFLECT = 30, F_REFRACT = 35, F_SCHLICK = 25;
+const double F_SHADE = 190, F_PREPARE = 60, F_REFLECT = 30, F_REFRACT = 35, F_SCHLICK = 25;
 
 struct DevBuf {
   void* p = nullptr;
@@ -70,7 +70,7 @@ struct rt355_ctx {
   bool counting = false, timing = false;
   int exact_cones = 0;
   int packet_gens = 2;  // generations 0..packet_gens-1 use the wave-packet traversal
-  DevBuf org, dir, hit_t, hit_uv, hit_prim, color, mix, child, hitlist, chunk_hits, ctl, io_in, io_out, io_out2;
+  DevBuf org, dir, hit_t, hit_uv, hit_prim, color, mixr, n12, shadow, child, blk_hits, blk_children, blk_base, ctl, io_in, io_out, io_out2;
   hipEvent_t ev[RT355_MAX_LAUNCH + 1];
   bool ev_ok = false;
   int n_cu = 256;
@@ -81,7 +81,7 @@ struct rt355_scene {
   int real_bits = 64;
   DevBuf nodes, prim_info, xform, tri, trin, materials;
   int32_t n_nodes = 0, n_bounded = 0, n_prims = 0, n_materials = 0, max_depth = 0;
-  bool any_secondary = false;
+  bool any_secondary = false, any_transparent = false;
   float light_pos[3], light_int[3];
   size_t device_bytes = 0;
 };
@@ -91,10 +91,10 @@ namespace {
 template <class R>
 DevScene<R> dev_scene(const rt355_scene* s) {
   DevScene<R> d;
-  d.nodes = (const BvhNode<R>*)s->nodes.p;
+  d.nodes = (const BvhNode<float>*)s->nodes.p;
   d.prim_info = (const PrimInfo*)s->prim_info.p;
   d.xform = (const DevXform<R>*)s->xform.p;
-  d.tri = (const DevTri<R>*)s->tri.p;
+  d.tri = (const DevTri*)s->tri.p;
   d.trin = (const DevTriNormals<R>*)s->trin.p;
   d.materials = (const DevMaterial<R>*)s->materials.p;
   d.n_nodes = s->n_nodes, d.n_bounded = s->n_bounded, d.n_prims = s->n_prims, d.n_materials = s->n_materials;
@@ -157,16 +157,20 @@ int ensure_pool(rt355_ctx* c, uint64_t n_primary, bool secondary, RayPool<R>& po
   if ((rc = c->hit_uv.ensure(cap * 2 * sizeof(R)))) return rc;
   if ((rc = c->hit_prim.ensure(cap * sizeof(int32_t)))) return rc;
   if ((rc = c->color.ensure(cap * 3 * sizeof(R)))) return rc;
-  if ((rc = c->mix.ensure(cap * 3 * sizeof(R)))) return rc;
+  if ((rc = c->mixr.ensure(cap * sizeof(R)))) return rc;
+  if ((rc = c->n12.ensure(cap * 2 * sizeof(R)))) return rc;
+  if ((rc = c->shadow.ensure(cap))) return rc;
   if ((rc = c->child.ensure(cap * 2 * sizeof(int32_t)))) return rc;
-  if ((rc = c->hitlist.ensure(cap * sizeof(int32_t)))) return rc;
-  const uint64_t cpg = cap / CHUNK + 2;
-  if ((rc = c->chunk_hits.ensure(cpg * (RT355_MAX_GEN + 1) * sizeof(uint32_t)))) return rc;
+  const uint64_t nblk = cap / BLOCK + 2;
+  if ((rc = c->blk_hits.ensure(nblk * sizeof(uint32_t)))) return rc;
+  if ((rc = c->blk_children.ensure(nblk * sizeof(uint32_t)))) return rc;
+  if ((rc = c->blk_base.ensure(nblk * sizeof(uint32_t)))) return rc;
   if ((rc = c->ctl.ensure(sizeof(FrameCtl)))) return rc;
   pool.org = (R*)c->org.p, pool.dir = (R*)c->dir.p, pool.hit_t = (R*)c->hit_t.p, pool.hit_uv = (R*)c->hit_uv.p;
-  pool.hit_prim = (int32_t*)c->hit_prim.p, pool.color = (R*)c->color.p, pool.mix = (R*)c->mix.p;
-  pool.child = (int32_t*)c->child.p, pool.hitlist = (int32_t*)c->hitlist.p;
-  pool.chunk_hits = (uint32_t*)c->chunk_hits.p, pool.chunks_per_gen = (int64_t)cpg;
+  pool.hit_prim = (int32_t*)c->hit_prim.p, pool.color = (R*)c->color.p, pool.mixr = (R*)c->mixr.p;
+  pool.n12 = (R*)c->n12.p, pool.shadow = (uint8_t*)c->shadow.p;
+  pool.child = (int32_t*)c->child.p;
+  pool.blk_hits = (uint32_t*)c->blk_hits.p, pool.blk_children = (uint32_t*)c->blk_children.p, pool.blk_base = (uint32_t*)c->blk_base.p;
   pool.capacity = (int64_t)cap;
   return RT355_OK;
 }
@@ -179,7 +183,8 @@ struct LaunchLog {
 // The frame: generation 0 rays are already in the pool (ids 0..n_primary).  Leaves the combined
 // generation-0 colours in pool.color[0..n_primary).
 template <class R, bool COUNT>
-int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, uint32_t n_primary, int max_depth, LaunchLog& log) {
+int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, uint32_t n_primary, int max_depth, const DevCamera<R>& cam,
+                    int out_mode, float* out_dev, LaunchLog& log) {
   DevScene<R> sc = dev_scene<R>(s);
   FrameCtl* ctl = (FrameCtl*)c->ctl.p;
   FrameCtl init;
@@ -188,7 +193,7 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, uint32
   HIP_TRY(hipMemcpyAsync(ctl, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
   const int depth = s->any_secondary ? max_depth : 0;  // no reflective / transparent material: one generation
   const int block = BLOCK;
-  const uint32_t grid0 = (n_primary + CHUNK - 1) / CHUNK;  // one block per chunk of rays
+  const uint32_t grid0 = (n_primary + BLOCK - 1) / BLOCK;  // one block per 256 rays
   const uint32_t grid_cap = (uint32_t)c->n_cu * 16;
   auto rec = [&](int kind, int gen) {
     if (c->timing && log.n < RT355_MAX_LAUNCH) HIP_TRY(hipEventRecord(c->ev[log.n], c->stream));
@@ -197,15 +202,24 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, uint32
   };
   for (int g = 0; g <= depth; ++g) {
     // generation g > 0 can hold at most twice the hits of g-1; its size is only known on the device
-    const uint32_t grid = g == 0 ? grid0 : std::min<uint32_t>(grid_cap, (uint32_t)((pool.capacity + CHUNK - 1) / CHUNK));
+    const uint32_t grid = g == 0 ? grid0 : std::min<uint32_t>(grid_cap, (uint32_t)((pool.capacity + BLOCK - 1) / BLOCK));
     int rc;
     if ((rc = rec(RT355_K_TRACE, g))) return rc;
     const bool packet = g < c->packet_gens;
     if (packet)
-      hipLaunchKernelGGL((k_trace<R, COUNT, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, log.n);
+      hipLaunchKernelGGL((k_trace<R, COUNT, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n);
     else
-      hipLaunchKernelGGL((k_trace<R, COUNT, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, log.n);
+      hipLaunchKernelGGL((k_trace<R, COUNT, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, pool.blk_hits, pool.blk_children, pool.blk_base, ctl, g, (long long)pool.capacity);
     log.n++;
+    if (s->any_transparent && g < depth) {  // n1 / n2 only matter while rays can still be spawned
+      if ((rc = rec(RT355_K_CONTAINER, g))) return rc;
+      if (packet)
+        hipLaunchKernelGGL((k_container<R, COUNT, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, log.n);
+      else
+        hipLaunchKernelGGL((k_container<R, COUNT, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, log.n);
+      log.n++;
+    }
     if ((rc = rec(RT355_K_SHADE, g))) return rc;
     if (packet)
       hipLaunchKernelGGL((k_shade<R, COUNT, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n);
@@ -213,11 +227,11 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, uint32
       hipLaunchKernelGGL((k_shade<R, COUNT, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n);
     log.n++;
   }
-  for (int g = depth - 1; g >= 0; --g) {
-    const uint32_t grid = g == 0 ? grid0 : std::min<uint32_t>(grid_cap, (uint32_t)((pool.capacity + CHUNK - 1) / CHUNK));
+  for (int g = depth; g >= 0; --g) {
+    const uint32_t grid = g == 0 ? grid0 : std::min<uint32_t>(grid_cap, (uint32_t)((pool.capacity + BLOCK - 1) / BLOCK));
     int rc;
     if ((rc = rec(RT355_K_COMBINE, g))) return rc;
-    hipLaunchKernelGGL((k_combine<R>), dim3(grid), dim3(block), 0, c->stream, pool, ctl, g);
+    hipLaunchKernelGGL((k_combine<R>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, cam, out_mode, out_dev);
     log.n++;
   }
   if (c->timing && log.n <= RT355_MAX_LAUNCH) HIP_TRY(hipEventRecord(c->ev[log.n], c->stream));
@@ -232,11 +246,14 @@ int finish_stats(rt355_ctx* c, const LaunchLog& log, double frame_ms, rt355_stat
   *overflow = h.overflow.v != 0;
   if (!st) return RT355_OK;
   memset(st, 0, sizeof(*st));
+  uint64_t hits_of[RT355_MAX_GEN + 1] = {0};
   for (int g = 0; g < RT355_MAX_GEN; ++g) {
-    st->radiance_rays[g] = h.gen_count[g].v;
-    st->hits[g] = h.hit_count[g].v;
-    st->total_radiance += h.gen_count[g].v;
-    st->total_shadow += h.hit_count[g].v;
+    const uint64_t hits = h.hit_count[g].v;
+    hits_of[g] = hits;
+    st->radiance_rays[g] = h.gen_count[g].v - h.holes[g].v;
+    st->hits[g] = hits;
+    st->total_radiance += h.gen_count[g].v - h.holes[g].v;
+    st->total_shadow += hits;
   }
   st->frame_ms = frame_ms;
   st->n_launch = log.n;
@@ -254,12 +271,14 @@ int finish_stats(rt355_ctx* c, const LaunchLog& log, double frame_ms, rt355_stat
       double fl = F_BOX * (double)w[0] + F_XFORM * (double)w[1];
       for (int k = 0; k < 8; ++k) prims += w[2 + k], fl += F_KIND[k] * (double)w[2 + k];
       st->launch_prim_tests[i] = prims;
+      st->launch_max_box_tests[i] = w[10];
+      st->launch_max_wave_clocks[i] = w[11];
       const int g = log.gen[i];
       if (log.kind[i] == RT355_K_SHADE) {
-        fl += F_SHADE * (double)h.hit_count[g].v;
-        // spawned children of this generation: every ray of generation g+1 (reflect or refract)
-        fl += 0.5 * (F_REFLECT + F_REFRACT) * (double)h.gen_count[g + 1].v;
+        // precompute for the shadow ray + spawned children (every ray of generation g+1)
+        fl += F_PREPARE * (double)hits_of[g] + 0.5 * (F_REFLECT + F_REFRACT) * (double)h.gen_count[g + 1].v;
       }
+      if (log.kind[i] == RT355_K_COMBINE) fl += F_SHADE * (double)hits_of[g];
       st->launch_flops[i] = fl;
     }
   }
@@ -282,11 +301,10 @@ int render_impl(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam
   hipLaunchKernelGGL((k_gen_primary<R>), dim3(grid0), dim3(block), 0, c->stream, dc, pool, (uint32_t)n_primary);
   LaunchLog log;
   if (c->counting)
-    rc = run_generations<R, true>(c, s, pool, (uint32_t)n_primary, max_depth, log);
+    rc = run_generations<R, true>(c, s, pool, (uint32_t)n_primary, max_depth, dc, out_mode, out_dev, log);
   else
-    rc = run_generations<R, false>(c, s, pool, (uint32_t)n_primary, max_depth, log);
+    rc = run_generations<R, false>(c, s, pool, (uint32_t)n_primary, max_depth, dc, out_mode, out_dev, log);
   if (rc) return rc;
-  hipLaunchKernelGGL((k_write_canvas<R>), dim3(grid0), dim3(block), 0, c->stream, pool, dc, (uint32_t)n_primary, out_mode, out_dev);
   HIP_TRY(hipGetLastError());
   bool overflow = false;
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -320,7 +338,7 @@ int rays_impl(rt355_ctx* c, const rt355_scene* s, const float* rays_host, size_t
     memset(&init, 0, sizeof(init));
     init.gen_count[0].v = (uint32_t)n;
     HIP_TRY(hipMemcpyAsync(c->ctl.p, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL((k_trace<R, false, false>), dim3((unsigned)((n + CHUNK - 1) / CHUNK)), dim3(block), 0, c->stream, sc, pool, (FrameCtl*)c->ctl.p, 0, 0);
+    hipLaunchKernelGGL((k_trace<R, false, false>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (FrameCtl*)c->ctl.p, 0, 0, 0);
     if ((rc = c->io_out.ensure(n * sizeof(double)))) return rc;
     if ((rc = c->io_out2.ensure(n * sizeof(int32_t)))) return rc;
     hipLaunchKernelGGL((k_export_hits<R>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (uint32_t)n, (double*)c->io_out.p, (int32_t*)c->io_out2.p);
@@ -331,15 +349,14 @@ int rays_impl(rt355_ctx* c, const rt355_scene* s, const float* rays_host, size_t
     return RT355_OK;
   }
   auto t0 = std::chrono::steady_clock::now();
-  if (c->counting)
-    rc = run_generations<R, true>(c, s, pool, (uint32_t)n, max_depth, log);
-  else
-    rc = run_generations<R, false>(c, s, pool, (uint32_t)n, max_depth, log);
-  if (rc) return rc;
   if ((rc = c->io_out.ensure(n * 3 * sizeof(float)))) return rc;
   DevCamera<R> dummy;
   memset(&dummy, 0, sizeof(dummy));
-  hipLaunchKernelGGL((k_write_canvas<R>), dim3(grid0), dim3(block), 0, c->stream, pool, dummy, (uint32_t)n, (int)OUT_LINEAR, (float*)c->io_out.p);
+  if (c->counting)
+    rc = run_generations<R, true>(c, s, pool, (uint32_t)n, max_depth, dummy, (int)OUT_LINEAR, (float*)c->io_out.p, log);
+  else
+    rc = run_generations<R, false>(c, s, pool, (uint32_t)n, max_depth, dummy, (int)OUT_LINEAR, (float*)c->io_out.p, log);
+  if (rc) return rc;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(rgb_out, c->io_out.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -352,12 +369,13 @@ int rays_impl(rt355_ctx* c, const rt355_scene* s, const float* rays_host, size_t
 template <class R>
 int upload_impl(rt355_ctx* c, const HostScene& hs, rt355_scene* s) {
   const size_t np = hs.prims.size(), nn = hs.nodes.size(), nm = hs.materials.size();
-  std::vector<BvhNode<R>> nodes(nn);
+  using NR = float;
+  std::vector<BvhNode<NR>> nodes(nn);
   for (size_t i = 0; i < nn; ++i) {
     for (int k = 0; k < 3; ++k) {
       // boxes were padded in double; when narrowing to float round outward
-      auto down = [](double v) { R r = (R)v; if ((double)r > v) r = std::nextafter(r, -std::numeric_limits<R>::infinity()); return r; };
-      auto up = [](double v) { R r = (R)v; if ((double)r < v) r = std::nextafter(r, std::numeric_limits<R>::infinity()); return r; };
+      auto down = [](double v) { NR r = (NR)v; if ((double)r > v) r = std::nextafter(r, -std::numeric_limits<NR>::infinity()); return r; };
+      auto up = [](double v) { NR r = (NR)v; if ((double)r < v) r = std::nextafter(r, std::numeric_limits<NR>::infinity()); return r; };
       nodes[i].lo0[k] = down(hs.nodes[i].lo0[k]), nodes[i].hi0[k] = up(hs.nodes[i].hi0[k]);
       nodes[i].lo1[k] = down(hs.nodes[i].lo1[k]), nodes[i].hi1[k] = up(hs.nodes[i].hi1[k]);
     }
@@ -370,18 +388,20 @@ int upload_impl(rt355_ctx* c, const HostScene& hs, rt355_scene* s) {
     const HostPrim& p = hs.prims[i];
     info[i].shape = p.shape;
     info[i].flags = p.flags | (p.material << PF_MAT_SHIFT);
+    if (hs.materials[p.material].reflective != 0.f) info[i].flags |= PF_REFLECTIVE;
+    if (hs.materials[p.material].transparency != 0.f) info[i].flags |= PF_TRANSPARENT;
     for (int k = 0; k < 12; ++k) xf[i].r[k] = (R)p.inv[k];
     xf[i].ymin = (R)p.ymin, xf[i].ymax = (R)p.ymax, xf[i].pad0 = xf[i].pad1 = 0;
     if ((p.flags & PF_KIND_MASK) >= RT355_TRIANGLE) any_tri = true;
   }
-  std::vector<DevTri<R>> tri(any_tri ? np : 0);
+  std::vector<DevTri> tri(any_tri ? np : 0);
   std::vector<DevTriNormals<R>> trin(any_tri ? np : 0);
   if (any_tri)
     for (size_t i = 0; i < np; ++i) {
       const HostPrim& p = hs.prims[i];
-      tri[i].shape = info[i].shape, tri[i].flags = info[i].flags;
+      tri[i].shape = info[i].shape, tri[i].flags = info[i].flags, tri[i].pad = 0;
       for (int k = 0; k < 3; ++k) {
-        tri[i].p1[k] = (R)p.p1[k], tri[i].e1[k] = (R)p.e1[k], tri[i].e2[k] = (R)p.e2[k];
+        tri[i].p1[k] = (float)p.p1[k], tri[i].p2[k] = (float)p.p2[k], tri[i].p3[k] = (float)p.p3[k];
         trin[i].n1[k] = (R)p.n1[k], trin[i].n2[k] = (R)p.n2[k], trin[i].n3[k] = (R)p.n3[k], trin[i].nf[k] = (R)p.nf[k];
       }
     }
@@ -401,14 +421,14 @@ int upload_impl(rt355_ctx* c, const HostScene& hs, rt355_scene* s) {
     return RT355_OK;
   };
   int rc;
-  if ((rc = put(s->nodes, nodes.data(), nn * sizeof(BvhNode<R>)))) return rc;
+  if ((rc = put(s->nodes, nodes.data(), nn * sizeof(BvhNode<NR>)))) return rc;
   if ((rc = put(s->prim_info, info.data(), np * sizeof(PrimInfo)))) return rc;
   if ((rc = put(s->xform, xf.data(), np * sizeof(DevXform<R>)))) return rc;
-  if ((rc = put(s->tri, tri.data(), tri.size() * sizeof(DevTri<R>)))) return rc;
+  if ((rc = put(s->tri, tri.data(), tri.size() * sizeof(DevTri)))) return rc;
   if ((rc = put(s->trin, trin.data(), trin.size() * sizeof(DevTriNormals<R>)))) return rc;
   if ((rc = put(s->materials, mats.data(), nm * sizeof(DevMaterial<R>)))) return rc;
   s->n_nodes = (int32_t)nn, s->n_bounded = hs.n_bounded, s->n_prims = (int32_t)np, s->n_materials = (int32_t)nm;
-  s->max_depth = hs.max_depth, s->any_secondary = hs.any_secondary;
+  s->max_depth = hs.max_depth, s->any_secondary = hs.any_secondary, s->any_transparent = hs.any_transparent;
   return RT355_OK;
 }
 
@@ -456,7 +476,7 @@ void rt355_ctx_destroy(rt355_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (DevBuf* b : {&c->org, &c->dir, &c->hit_t, &c->hit_uv, &c->hit_prim, &c->color, &c->mix, &c->child, &c->hitlist, &c->chunk_hits, &c->ctl, &c->io_in, &c->io_out, &c->io_out2}) b->release();
+  for (DevBuf* b : {&c->org, &c->dir, &c->hit_t, &c->hit_uv, &c->hit_prim, &c->color, &c->mixr, &c->n12, &c->shadow, &c->child, &c->blk_hits, &c->blk_children, &c->blk_base, &c->ctl, &c->io_in, &c->io_out, &c->io_out2}) b->release();
   if (c->ev_ok)
     for (int i = 0; i <= RT355_MAX_LAUNCH; ++i) (void)hipEventDestroy(c->ev[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -19,8 +19,6 @@ constexpr int TILE_PIX = TILE * TILE;
 constexpr int STACK_DEPTH = 64;      // traversal stack entries; the builder keeps the tree shallower
 constexpr int LDS_STACK = 24;        // of which this many live in LDS (one column per lane); the rest in scratch
 constexpr int BLOCK = 256;           // threads per block of the traversal kernels
-constexpr int CHUNK_K = 2;           // rays per thread per chunk
-constexpr int CHUNK = BLOCK * CHUNK_K;  // a block compacts its hits / children once per chunk: one atomic per chunk
 constexpr uint32_t LEAF_FIRST_MASK = 0x1FFFFFFu;  // leaf reference ~c: first | tri-only flag << 25 | count << 26
 constexpr uint32_t LEAF_TRI_BIT = 1u << 25;       // every prim of the leaf is a triangle with identity transform
 constexpr int MAX_TREE_DEPTH = 60;
@@ -31,6 +29,8 @@ constexpr int N_WORK_COUNTERS = 12;  // per launch: [0] box tests, [1] xforms, [
 constexpr int PF_KIND_MASK = 7;
 constexpr int PF_CLOSED = 8;
 constexpr int PF_IDENTITY = 16;  // transformation is exactly the identity: the ray is used as is
+constexpr int PF_REFLECTIVE = 32;   // material.reflective != 0: a hit may spawn a reflected ray
+constexpr int PF_TRANSPARENT = 64;  // material.transparency != 0: a hit may spawn a refracted ray
 constexpr int PF_MAT_SHIFT = 8;
 
 struct PrimInfo {
@@ -61,10 +61,13 @@ struct DevXform {  // rows 0..2 of the inverse transformation (affine): x' = r0 
   R pad0, pad1;
 };
 
-template <class R>
-struct alignas(16) DevTri {  // Moeller-Trumbore operands, object space (src/triangle.rs:83-84)
-  R p1[3], e1[3], e2[3];
+// Triangle record: the three vertices as the f32 values the host handed over (src/triangle.rs:10-12),
+// 48 bytes.  The edges e1 = p2 - p1, e2 = p3 - p1 (src/triangle.rs:83-84) are formed in the kernel, in R:
+// in double the difference of two floats is exact, in float it is the reference's own subtraction.
+struct alignas(16) DevTri {
+  float p1[3], p2[3], p3[3];
   int32_t shape, flags;  // copy of prim_info: one fetch per triangle test
+  int32_t pad;
 };
 
 template <class R>
@@ -74,10 +77,11 @@ struct DevTriNormals {  // smooth triangle: n1,n2,n3; flat triangle: nf (src/tri
 
 template <class R>
 struct DevScene {
-  const BvhNode<R>* nodes;        // n_nodes (0 when there is no bounded prim)
+  const BvhNode<float>* nodes;    // n_nodes (0 when there is no bounded prim); boxes are stored in float,
+                                  // rounded outward, whatever R is: half the bytes per visit, same culling
   const PrimInfo* prim_info;      // n_prims
   const DevXform<R>* xform;       // n_prims
-  const DevTri<R>* tri;           // n_prims (valid for triangle kinds)
+  const DevTri* tri;              // n_prims (valid for triangle kinds)
   const DevTriNormals<R>* trin;   // n_prims (valid for triangle kinds)
   const DevMaterial<R>* materials;
   int32_t n_nodes, n_bounded, n_prims, n_materials;
@@ -101,13 +105,17 @@ struct RayPool {
   R* hit_t;    // nearest t >= 0
   R* hit_uv;   // 2 per ray (smooth triangles)
   int32_t* hit_prim;   // prim id, -1 = miss
-  R* color;    // 3 per ray: surface colour, replaced by the combined colour in the combine pass
-  R* mix;      // 3 per ray: reflective, transparency, schlick reflectance (< 0: plain sum)
+  R* color;    // 3 per ray: colour of the ray (color_at), written by the combine pass
+  R* mixr;     // schlick reflectance of the hit (< 0: plain sum)
+  R* n12;      // 2 per ray: n1, n2 of a hit on a transparent shape
   int32_t* child;      // 2 per ray: reflected, refracted child ray id (-1 = none)
-  int32_t* hitlist;    // ids of the rays that hit something: chunk c of a generation owns the slots
-                       // [gen start + c*CHUNK, +chunk_hits), filled in ray order (no global atomics)
-  uint32_t* chunk_hits;  // [generation][chunk] number of hits of the chunk
-  int64_t chunks_per_gen;
+  uint8_t* shadow;     // is_shadowed(over_point) of the hit
+  // Child-ray slots are handed out without atomics: k_trace leaves, per block of BLOCK rays, the number of
+  // hits and an upper bound of the children they can spawn; k_scan turns the bounds into exclusive
+  // prefixes; k_shade places its children at prefix + rank inside the block.
+  uint32_t* blk_hits;
+  uint32_t* blk_children;
+  uint32_t* blk_base;
   int64_t capacity;
 };
 
@@ -119,8 +127,10 @@ struct alignas(128) PaddedCounter {
   uint32_t pad[31];
 };
 struct FrameCtl {
-  PaddedCounter gen_count[RT355_MAX_GEN + 1];
+  PaddedCounter gen_count[RT355_MAX_GEN + 1];  // slots of the generation (children are placed by upper bound)
   PaddedCounter hit_count[RT355_MAX_GEN + 1];
+  PaddedCounter holes[RT355_MAX_GEN + 1];      // slots of the generation that hold no ray (refraction that turned
+                                               // out to be total internal reflection)
   PaddedCounter overflow;
   unsigned long long work[RT355_MAX_LAUNCH][N_WORK_COUNTERS];
 };
@@ -132,7 +142,7 @@ struct HostPrim {
   int32_t material;
   double inv[12];
   double ymin, ymax;
-  double p1[3], e1[3], e2[3];
+  double p1[3], p2[3], p3[3];
   double n1[3], n2[3], n3[3], nf[3];
   double lo[3], hi[3];
   bool bounded;
@@ -149,7 +159,8 @@ struct HostScene {
   std::vector<HostNode> nodes;
   int32_t max_depth = 0;
   std::vector<rt355_material> materials;
-  bool any_secondary = false;  // some material is reflective or transparent
+  bool any_secondary = false;    // some material is reflective or transparent
+  bool any_transparent = false;  // some material is transparent
 };
 
 // Returns 0 or RT355_EINVAL (message in err).  pad_rel: relative outward padding of every box.

@@ -236,6 +236,7 @@ int build_host_scene(const rt355_shape_desc* shapes, size_t n, double pad_rel, i
       it = mat_index.emplace(key, (int)out.materials.size()).first;
       out.materials.push_back(d.mat);
       if (d.mat.reflective != 0.f || d.mat.transparency != 0.f) out.any_secondary = true;
+      if (d.mat.transparency != 0.f) out.any_transparent = true;
     }
     p.material = it->second;
     p.flags = d.kind | (d.closed ? PF_CLOSED : 0) | (is_identity(d.m) ? PF_IDENTITY : 0);
@@ -278,9 +279,7 @@ int build_host_scene(const rt355_shape_desc* shapes, size_t n, double pad_rel, i
       case RT355_SMOOTH_TRIANGLE: {
         for (int k = 0; k < 3; ++k) {
           if (!std::isfinite(d.p1[k]) || !std::isfinite(d.p2[k]) || !std::isfinite(d.p3[k])) return fail("non-finite vertex", i);
-          p.p1[k] = d.p1[k];
-          p.e1[k] = (double)d.p2[k] - (double)d.p1[k];
-          p.e2[k] = (double)d.p3[k] - (double)d.p1[k];
+          p.p1[k] = d.p1[k], p.p2[k] = d.p2[k], p.p3[k] = d.p3[k];
           p.n1[k] = d.n1[k], p.n2[k] = d.n2[k], p.n3[k] = d.n3[k];
         }
         // flat normal: local e2 = p3 - p2, local e1 = p2 - p1, normal = normalize(e2 x e1)

@@ -11,5 +11,5 @@ import json
 l=[x for x in open('gpurun_out/bench.log') if x.startswith('{')][-1]
 d=json.loads(l)
 print("value", d["value"], d["unit"], "ms/step", d["ms_per_step"], "frac", d["roofline"]["frac"], d["roofline"]["kernel"], "frame_kernel_ms", d["roofline"]["frame_kernel_ms"])
-print(" ".join(f'{x["kernel"][2:5]}{x["gen"]}:{x["ms"]:.3f}' for x in d["roofline"]["launches"]))
+print(" ".join(f'{x["kernel"][2:6]}{x["gen"]}:{x["ms"]:.3f}' for x in d["roofline"]["launches"]))
 PY
