@@ -92,21 +92,23 @@ typedef struct rt355_camera_desc {
 } rt355_camera_desc;
 
 #define RT355_MAX_GEN 8     /* generations 0..max_depth; max_depth <= 7 */
-#define RT355_MAX_LAUNCH 32 /* per-frame kernel launches recorded in rt355_stats */
+#define RT355_MAX_LAUNCH 48 /* per-frame kernel launches recorded in rt355_stats */
 
 /* Kernel classes recorded per launch in rt355_stats.launch_kind. */
 enum rt355_launch_kind {
-  RT355_K_TRACE = 1,   /* nearest-hit traversal (generation 0 also generates the primary rays) */
-  RT355_K_SHADE = 2,   /* precompute + shadow ray + child-ray spawn (reflect / refract / schlick)   */
-  RT355_K_COMBINE = 3, /* Phong lighting + child colours folded into their parent; generation 0
-                          writes the canvas */
-  RT355_K_CONTAINER = 4 /* n1 / n2 of hits on transparent shapes */
+  RT355_K_TRACE = 1,     /* nearest-hit traversal of one generation, followed by the slot prefix sums */
+  RT355_K_SHADE = 2,     /* shadow rays of one generation (is_shadowed)                              */
+  RT355_K_COMBINE = 3,   /* Phong lighting + child colours folded into their parent; generation 0
+                            writes the canvas */
+  RT355_K_SPAWN = 5      /* n1 / n2, reflect / refract / schlick: writes the rays of the next generation */
 };
 
 /* Per-frame statistics.  Ray counts are always filled.  Work counters (box_tests ... flops) are
  * filled only when the context is in counting mode (rt355_ctx_set_counting), which runs
  * instrumented kernels and is not meant to be timed.  Launch times are filled when timing mode
- * is on (rt355_ctx_set_timing): HIP events around every launch on the context's stream. */
+ * is on (rt355_ctx_set_timing): HIP events around every launch, with all launches on ONE stream.
+ * Outside these two modes the shadow launches run on a second stream beside the others, so a
+ * frame takes less than the sum of its launch times. */
 typedef struct rt355_stats {
   uint64_t radiance_rays[RT355_MAX_GEN]; /* one per color_at call (src/world.rs:58)      */
   uint64_t hits[RT355_MAX_GEN];          /* = shadow rays: one per is_shadowed call (:105) */

@@ -3,14 +3,15 @@
 // The reference renders a pixel by recursion: Camera::render -> World::color_at -> shade_hit ->
 // is_shadowed / reflected_color / refracted_color -> color_at ... (src/camera.rs:74-88,
 // src/world.rs:58-127).  Here the recursion is unrolled into GENERATIONS of rays (generation g holds the
-// rays whose `remaining` is max_depth - g) and each generation runs three data-parallel kernels:
+// rays whose `remaining` is max_depth - g) and each generation runs data-parallel kernels:
 //
-//   k_trace    World::intersect + Intersections::hit        one thread per ray, BVH traversal
-//   k_shade    prepare_computation + is_shadowed + lighting  one thread per ray that hit, spawns child rays into
-//              + reflect / refract / schlick                 generation g+1 (wave64 ballot compaction)
-//   k_combine  shade_hit's final sum                          run from the deepest generation back to 0
+//   k_trace      World::intersect + Intersections::hit     one thread per ray, BVH traversal
+//   k_scan       (no counterpart)                          child-ray slots of the generation: prefix sums
+//   k_spawn      n1 / n2 + reflect / refract / schlick     writes the rays of generation g+1
+//   k_shadow     is_shadowed                               off the critical path: second stream
+//   k_combine    lighting + shade_hit's final sum          run from the deepest generation back to 0
 //
-// Every hit keeps its own record (surface colour, the two child ids, the mix weights), so k_combine
+// Every hit keeps its own record (the two child ids, the mix weight, the shadow flag), so k_combine
 // evaluates exactly the reference's expression  surface + reflected*R + refracted*(1-R)  (or
 // surface + refracted + reflected) per hit, in the reference's order, with no atomics on colours: the
 // image does not depend on queue order and is bit-identical across tile splits.
@@ -75,6 +76,7 @@ struct Work {  // per-thread work counters (counting mode only)
 };
 template <bool COUNT> RT_FN void flush_work(FrameCtl* ctl, int launch, const Work& w) {
   if constexpr (COUNT) {
+    if (launch >= RT355_MAX_LAUNCH) return;
     if (w.box) atomicAdd(&ctl->work[launch][0], (unsigned long long)w.box);
     if (w.box) atomicMax(&ctl->work[launch][10], (unsigned long long)w.box);  // longest traversal of one lane
     if (w.xf) atomicAdd(&ctl->work[launch][1], (unsigned long long)w.xf);
@@ -228,6 +230,56 @@ RT_FN bool tri_hit(const DevTri& T, V3<R> o, V3<R> d, R& t, R& u, R& v) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Box culling in single precision, conservative.  The boxes only decide which primitives get tested; the
+// tests themselves stay in R.  So the slab arithmetic may run in float, as long as it never reports a
+// miss for a box the exact ray touches.  With P a box plane, exact entry/exit parameters are
+// (P - o) / d.  Here they are evaluated as fma(P, id, c) with id = float(1/d) and c = -float(o/d) -/+ E;
+// the rounding of id, of o/d and of the fma together is below (|P| + |o|) * |id| * 2^-23, and E is twice
+// that with |P| replaced by the largest box coordinate of the scene, subtracted on the near side and added
+// on the far side.  1/d is clamped to +-1e28, so axis-parallel rays stay finite.  The sign of id picks the
+// near plane, so there is no min / max per axis.
+// ------------------------------------------------------------------------------------------------
+struct SlabRay {
+  float ix, iy, iz;  // 1 / d
+  float nx, ny, nz;  // near-side constants
+  float fx, fy, fz;  // far-side constants
+};
+template <class R>
+RT_FN SlabRay make_slab_ray(V3<R> o, V3<R> d, float abs_max) {
+  SlabRay s;
+  auto axis = [&](R oc, R dc, float& i, float& n, float& f) {
+    double id = 1.0 / (double)dc;
+    if (!(fabs(id) < 1e28)) id = copysign(1e28, (double)dc);
+    const double oid = (double)oc * id;
+    i = (float)id;
+    const float e = (abs_max + fabsf((float)oc) * 1.0000002f) * fabsf(i) * 2.3841858e-7f;  // 2^-22
+    n = -(float)oid - e;
+    f = -(float)oid + e;
+  };
+  axis(o.x, d.x, s.ix, s.nx, s.fx);
+  axis(o.y, d.y, s.iy, s.ny, s.fy);
+  axis(o.z, d.z, s.iz, s.nz, s.fz);
+  return s;
+}
+// [tmin, tmax] of the visitor, widened to the enclosing floats
+template <class R>
+RT_FN void slab_interval(R tmin, R tmax, float& lo, float& hi) {
+  const float a = (float)tmin, b = (float)tmax;
+  lo = a - fabsf(a) * 1.1920929e-7f;
+  hi = b + fabsf(b) * 1.1920929e-7f;
+}
+// true when the ray may touch the box within [tlo, thi]; tn = (conservative) entry parameter
+RT_FN bool slab_test(const SlabRay& s, float lox, float loy, float loz, float hix, float hiy, float hiz, float tlo, float thi, float& tn) {
+  const bool px = s.ix >= 0.f, py = s.iy >= 0.f, pz = s.iz >= 0.f;
+  const float nx = fmaf(px ? lox : hix, s.ix, s.nx), fx = fmaf(px ? hix : lox, s.ix, s.fx);
+  const float ny = fmaf(py ? loy : hiy, s.iy, s.ny), fy = fmaf(py ? hiy : loy, s.iy, s.fy);
+  const float nz = fmaf(pz ? loz : hiz, s.iz, s.nz), fz = fmaf(pz ? hiz : loz, s.iz, s.fz);
+  tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, tlo));
+  const float tf = fminf(fminf(fx, fy), fminf(fz, thi));
+  return tn <= tf;
+}
+
+// ------------------------------------------------------------------------------------------------
 // BVH traversal.  Replaces the brute-force loop of World::intersect (src/world.rs:35-44).
 // Visitor: tmin(), tmax() give the live ray interval; prim(p) tests one prim of any kind, tri(p, T) one
 // identity-transform triangle whose record is already loaded; both return true to stop.
@@ -239,25 +291,17 @@ RT_FN void traverse(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work& wk,
   for (int p = sc.n_bounded; p < sc.n_prims; ++p)
     if (vis.prim(p)) return;
   if (sc.n_nodes == 0) return;
-  const V3<R> id = {R(1) / d.x, R(1) / d.y, R(1) / d.z};
+  const SlabRay sr = make_slab_ray(o, d, sc.box_abs_max);
   int spill[STACK_DEPTH - LDS_STACK];
   int sp = 0;
   int cur = 0;
   for (;;) {
     if (cur >= 0) {
       const BvhNode<float> N = sc.nodes[cur];
-      const R tmin = vis.tmin(), tmax = vis.tmax();
-      R ax0 = (R(N.lo0[0]) - o.x) * id.x, ax1 = (R(N.hi0[0]) - o.x) * id.x;
-      R ay0 = (R(N.lo0[1]) - o.y) * id.y, ay1 = (R(N.hi0[1]) - o.y) * id.y;
-      R az0 = (R(N.lo0[2]) - o.z) * id.z, az1 = (R(N.hi0[2]) - o.z) * id.z;
-      R an = fmax(fmax(fmin(ax0, ax1), fmin(ay0, ay1)), fmax(fmin(az0, az1), tmin));
-      R af = fmin(fmin(fmax(ax0, ax1), fmax(ay0, ay1)), fmin(fmax(az0, az1), tmax));
-      R bx0 = (R(N.lo1[0]) - o.x) * id.x, bx1 = (R(N.hi1[0]) - o.x) * id.x;
-      R by0 = (R(N.lo1[1]) - o.y) * id.y, by1 = (R(N.hi1[1]) - o.y) * id.y;
-      R bz0 = (R(N.lo1[2]) - o.z) * id.z, bz1 = (R(N.hi1[2]) - o.z) * id.z;
-      R bn = fmax(fmax(fmin(bx0, bx1), fmin(by0, by1)), fmax(fmin(bz0, bz1), tmin));
-      R bf = fmin(fmin(fmax(bx0, bx1), fmax(by0, by1)), fmin(fmax(bz0, bz1), tmax));
-      const bool ha = an <= af, hb = bn <= bf;
+      float tlo, thi, an, bn;
+      slab_interval(vis.tmin(), vis.tmax(), tlo, thi);
+      const bool ha = slab_test(sr, N.lo0[0], N.lo0[1], N.lo0[2], N.hi0[0], N.hi0[1], N.hi0[2], tlo, thi, an);
+      const bool hb = slab_test(sr, N.lo1[0], N.lo1[1], N.lo1[2], N.hi1[0], N.hi1[1], N.hi1[2], tlo, thi, bn);
       const int c0 = N.c0, c1 = N.c1;
       if constexpr (COUNT) wk.box += 2;
       if (ha && hb) {
@@ -329,8 +373,7 @@ RT_FN void traverse_packet(const DevScene<R>& sc, V3<R> o, V3<R> d, bool live, V
   for (int p = sc.n_bounded; p < sc.n_prims; ++p)
     if (live && vis.prim(p)) live = false;
   if (sc.n_nodes == 0) return;
-  const V3<R> id = {R(1) / d.x, R(1) / d.y, R(1) / d.z};
-  const V3<R> oid = {o.x * id.x, o.y * id.y, o.z * id.z};
+  const SlabRay sr = make_slab_ray(o, d, sc.box_abs_max);
   int sp = 0;
   int cur = 0;
   for (;;) {
@@ -339,19 +382,10 @@ RT_FN void traverse_packet(const DevScene<R>& sc, V3<R> o, V3<R> d, bool live, V
       cptr<float> q = (cptr<float>)(const float*)&sc.nodes[cur];
       cptr<int32_t> qc = (cptr<int32_t>)(const int32_t*)&sc.nodes[cur].c0;
       const int c0 = qc[0], c1 = qc[1];
-      const R tmin = vis.tmin(), tmax = vis.tmax();
-      // (lo - o) * id == lo * id - o * id up to rounding; boxes are padded by far more than that
-      R ax0 = R(q[0]) * id.x - oid.x, ax1 = R(q[3]) * id.x - oid.x;
-      R ay0 = R(q[1]) * id.y - oid.y, ay1 = R(q[4]) * id.y - oid.y;
-      R az0 = R(q[2]) * id.z - oid.z, az1 = R(q[5]) * id.z - oid.z;
-      R an = fmax(fmax(fmin(ax0, ax1), fmin(ay0, ay1)), fmax(fmin(az0, az1), tmin));
-      R af = fmin(fmin(fmax(ax0, ax1), fmax(ay0, ay1)), fmin(fmax(az0, az1), tmax));
-      R bx0 = R(q[6]) * id.x - oid.x, bx1 = R(q[9]) * id.x - oid.x;
-      R by0 = R(q[7]) * id.y - oid.y, by1 = R(q[10]) * id.y - oid.y;
-      R bz0 = R(q[8]) * id.z - oid.z, bz1 = R(q[11]) * id.z - oid.z;
-      R bn = fmax(fmax(fmin(bx0, bx1), fmin(by0, by1)), fmax(fmin(bz0, bz1), tmin));
-      R bf = fmin(fmin(fmax(bx0, bx1), fmax(by0, by1)), fmin(fmax(bz0, bz1), tmax));
-      const bool ha = live && an <= af, hb = live && bn <= bf;
+      float tlo, thi, an, bn;
+      slab_interval(vis.tmin(), vis.tmax(), tlo, thi);
+      const bool ha = slab_test(sr, q[0], q[1], q[2], q[3], q[4], q[5], tlo, thi, an) && live;
+      const bool hb = slab_test(sr, q[6], q[7], q[8], q[9], q[10], q[11], tlo, thi, bn) && live;
       if constexpr (COUNT) wk.box += live ? 2 : 0;
       const unsigned long long ua = __ballot(ha), ub = __ballot(hb);
       if (ua && ub) {
@@ -582,7 +616,7 @@ __global__ void __launch_bounds__(256) k_trace(DevScene<R> sc, RayPool<R> pool, 
     if constexpr (COUNT) {
       // longest traversal of one wave, in shader clocks (all lanes reconverge here)
       const unsigned long long dt = (unsigned long long)(clock64() - t_start);
-      if ((threadIdx.x & 63u) == 0) atomicMax(&ctl->work[launch][11], dt);
+      if ((threadIdx.x & 63u) == 0 && launch < RT355_MAX_LAUNCH) atomicMax(&ctl->work[launch][11], dt);
     }
     uint32_t n_child = 0;
     const bool hit = valid && vis.best_p >= 0;
@@ -745,7 +779,7 @@ RT_FN V3<R> lighting(const DevScene<R>& sc, const DevMaterial<R>& m, V3<R> point
 
 // ------------------------------------------------------------------------------------------------
 // The part of prepare_computation (src/intersection.rs:60-85) that needs no intersection list.  It is
-// evaluated from the ray and hit records wherever it is needed (k_shade twice, k_combine once) instead of
+// evaluated from the ray and hit records wherever it is needed (k_shadow, k_spawn, k_combine) instead of
 // being carried in registers or in memory: a few dozen flops against a dozen live doubles.
 // ------------------------------------------------------------------------------------------------
 template <class R>
@@ -772,12 +806,96 @@ RT_FN Prepared<R> prepare(const DevScene<R>& sc, const RayPool<R>& pool, uint32_
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_container: n1 / n2 of prepare_computation (src/intersection.rs:86-127) for the hits of generation
-// `gen` on transparent shapes.  Launched only for scenes with a transparent material and only while
-// rays can still be spawned: n1 / n2 feed refracted_color and schlick, which multiply black otherwise.
+// container_indices: n1 / n2 of prepare_computation (src/intersection.rs:86-127) for a hit on a transparent
+// shape.  The reference walks the whole sorted intersection list of the ray; what decides n1 / n2 is only
+// (a) how many of the hit shape's own intersections come before the hit and (b) the last shape entered and
+// not left before the hit, which is found by walking BACKWARDS from the hit: the nearest intersection
+// behind it whose shape has an odd number of intersections before the hit.
+// Called by every lane of the wave (the packet traversal needs them all); `need` marks the lanes that
+// want an answer.
 // ------------------------------------------------------------------------------------------------
 template <class R, bool COUNT, bool PACKET>
-__global__ void __launch_bounds__(256) k_container(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int launch) {
+RT_FN void container_indices(const DevScene<R>& sc, bool need, int p, PrimInfo info, V3<R> o, V3<R> d, R t_hit, int* lds, Work& wk, R& n1, R& n2) {
+  const R t = need ? t_hit : R(1);
+  // the hit shape's own intersections, emission order
+  R h0 = R(0), h1 = R(0), h2 = R(0), h3 = R(0);
+  int nh = 0;
+  if (need)
+    prim_hits<R, COUNT>(sc, p, info.flags, o, d, wk, [&](R tt, R, R, int em) {
+      if (em == 0) h0 = tt; else if (em == 1) h1 = tt; else if (em == 2) h2 = tt; else if (em == 3) h3 = tt;
+      nh = em + 1;
+    });
+  const R ht[4] = {h0, h1, h2, h3};
+  // the entry the reference treats as "the hit" last: same t, latest emission
+  int m_last = 0;
+  R best = inf<R>();
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k < nh) {
+      const R dd = fabs(ht[k] - t);
+      if (dd <= best) best = dd, m_last = k;
+    }
+  R tm = t;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (nh && k == m_last) tm = ht[k];
+  int c_before = 0;
+  R hmt = R(0);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k < nh && (ht[k] < tm || (ht[k] == tm && k < m_last))) {
+      if (c_before == 0 || ht[k] >= hmt) hmt = ht[k];
+      ++c_before;
+    }
+  // the container's last element among the OTHER shapes: walk backwards from the hit
+  const V3<R> rd = R(-1) * d;
+  bool searching = need, found = false;
+  int other_flags = 0, other_s = -1;
+  R other_t = R(0);
+  R bound_t = t;
+  int bound_s = info.shape;
+  for (int step = 0; step < 4096; ++step) {
+    if (PACKET ? (__ballot(searching) == 0ull) : !searching) break;
+    BackwardVis<R, COUNT> bv(sc, o, rd, p, bound_t, bound_s, wk);
+    if constexpr (PACKET) {
+      traverse_packet<R, COUNT>(sc, o, rd, searching, bv, wk, lds);
+    } else {
+      if (searching) traverse<R, COUNT>(sc, o, rd, bv, wk, lds);
+    }
+    if (searching) {
+      if (!bv.have) {
+        searching = false;
+      } else {
+        // is that shape present, i.e. does it have an odd number of intersections before the hit?
+        int cnt = 0;
+        prim_hits<R, COUNT>(sc, bv.cp, bv.cflags, o, d, wk, [&](R tt, R, R, int) {
+          if (tt < t || (tt == t && bv.cs < info.shape)) ++cnt;
+        });
+        if (cnt & 1) {
+          found = true, other_flags = bv.cflags, other_s = bv.cs, other_t = bv.ct;
+          searching = false;
+        } else {
+          bound_t = bv.ct, bound_s = bv.cs;
+        }
+      }
+    }
+  }
+  const R own = sc.materials[info.flags >> PF_MAT_SHIFT].refractive;
+  const R other = found ? sc.materials[other_flags >> PF_MAT_SHIFT].refractive : R(1);
+  const bool h_before = (c_before & 1) != 0;
+  const bool own_last = h_before && (!found || hmt > other_t || (hmt == other_t && info.shape > other_s));
+  n1 = own_last ? own : other;
+  n2 = ((c_before + 1) & 1) ? own : other;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_shadow: is_shadowed (src/world.rs:45-57) for every hit of generation `gen`.  Nothing on the way to the
+// next generation depends on the result (only k_combine reads it), so the host runs these launches on a
+// second stream, beside the trace / spawn chain of the later generations.
+// One thread per ray; lanes whose ray missed idle.
+// ------------------------------------------------------------------------------------------------
+template <class R, bool COUNT, bool PACKET>
+__global__ void __launch_bounds__(256) k_shadow(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int launch) {
   uint32_t start, gcount;
   gen_range(ctl, gen, pool.capacity, start, gcount);
   __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
@@ -787,104 +905,43 @@ __global__ void __launch_bounds__(256) k_container(DevScene<R> sc, RayPool<R> po
     const uint32_t i = rbase + threadIdx.x;
     const uint32_t r = start + (i < gcount ? i : 0u);
     const int p_raw = pool.hit_prim[r];
-    const int p = (i < gcount && p_raw >= 0) ? p_raw : 0;
+    const bool valid = i < gcount && p_raw >= 0;
+    if (__ballot(valid) == 0ull) continue;  // wave-uniform
+    const int p = valid ? p_raw : 0;
     const PrimInfo info = sc.prim_info[p];
-    const bool need = i < gcount && p_raw >= 0 && (info.flags & PF_TRANSPARENT);
-    if (__ballot(need) == 0ull) continue;  // wave-uniform
-    const V3<R> o = ld3(pool.org + 3ull * r), d = ld3(pool.dir + 3ull * r);
-    const R t = need ? pool.hit_t[r] : R(1);
-    // the hit shape's own intersections, emission order
-    R h0 = R(0), h1 = R(0), h2 = R(0), h3 = R(0);
-    int nh = 0;
-    if (need)
-      prim_hits<R, COUNT>(sc, p, info.flags, o, d, wk, [&](R tt, R, R, int em) {
-        if (em == 0) h0 = tt; else if (em == 1) h1 = tt; else if (em == 2) h2 = tt; else if (em == 3) h3 = tt;
-        nh = em + 1;
-      });
-    const R ht[4] = {h0, h1, h2, h3};
-    // the entry the reference treats as "the hit" last: same t, latest emission
-    int m_last = 0;
-    R best = inf<R>();
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (k < nh) {
-        const R dd = fabs(ht[k] - t);
-        if (dd <= best) best = dd, m_last = k;
-      }
-    R tm = t;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (nh && k == m_last) tm = ht[k];
-    int c_before = 0;
-    R hmt = R(0);
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (k < nh && (ht[k] < tm || (ht[k] == tm && k < m_last))) {
-        if (c_before == 0 || ht[k] >= hmt) hmt = ht[k];
-        ++c_before;
-      }
-    // the container's last element among the OTHER shapes: walk backwards from the hit
-    const V3<R> rd = R(-1) * d;
-    bool searching = need, found = false;
-    int other_flags = 0, other_s = -1;
-    R other_t = R(0);
-    R bound_t = t;
-    int bound_s = info.shape;
-    for (int step = 0; step < 4096; ++step) {
-      if (PACKET ? (__ballot(searching) == 0ull) : !searching) break;
-      BackwardVis<R, COUNT> bv(sc, o, rd, p, bound_t, bound_s, wk);
-      if constexpr (PACKET) {
-        traverse_packet<R, COUNT>(sc, o, rd, searching, bv, wk, lds);
-      } else {
-        if (searching) traverse<R, COUNT>(sc, o, rd, bv, wk, lds);
-      }
-      if (searching) {
-        if (!bv.have) {
-          searching = false;
-        } else {
-          // is that shape present, i.e. does it have an odd number of intersections before the hit?
-          int cnt = 0;
-          prim_hits<R, COUNT>(sc, bv.cp, bv.cflags, o, d, wk, [&](R tt, R, R, int) {
-            if (tt < t || (tt == t && bv.cs < info.shape)) ++cnt;
-          });
-          if (cnt & 1) {
-            found = true, other_flags = bv.cflags, other_s = bv.cs, other_t = bv.ct;
-            searching = false;
-          } else {
-            bound_t = bv.ct, bound_s = bv.cs;
-          }
-        }
-      }
+    V3<R> over_point = {R(0), R(0), R(0)};
+    if (valid) over_point = prepare(sc, pool, r, p, info.flags).over_point;
+    const V3<R> lv = ld3(sc.light_pos) - over_point;
+    const R distance = sqrt(dot(lv, lv));
+    const V3<R> ldir = {lv.x / distance, lv.y / distance, lv.z / distance};
+    AnyVis<R, COUNT> av(sc, over_point, ldir, distance + eps<R>(), wk);
+    if constexpr (PACKET) {
+      traverse_packet<R, COUNT>(sc, over_point, ldir, valid, av, wk, lds);
+    } else {
+      if (valid) traverse<R, COUNT>(sc, over_point, ldir, av, wk, lds);
     }
-    if (need) {
-      const R own = sc.materials[info.flags >> PF_MAT_SHIFT].refractive;
-      const R other = found ? sc.materials[other_flags >> PF_MAT_SHIFT].refractive : R(1);
-      const bool h_before = (c_before & 1) != 0;
-      const bool own_last = h_before && (!found || hmt > other_t || (hmt == other_t && info.shape > other_s));
-      pool.n12[2ull * r] = own_last ? own : other;                  // n1
-      pool.n12[2ull * r + 1] = ((c_before + 1) & 1) ? own : other;  // n2
-    }
+    if (valid) pool.shadow[r] = av.found ? 1 : 0;
   }
   flush_work<COUNT>(ctl, launch, wk);
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_shade: is_shadowed (src/world.rs:45-57) for every hit of generation `gen`, then the set-up of its
-// reflected / refracted rays (src/world.rs:68-102) and the Schlick reflectance (src/computation.rs:20-33).
-// One thread per ray; lanes whose ray missed idle.  Primary and mirror rays hit or miss in large screen
-// regions, so most waves are (nearly) full or skipped outright.
+// k_spawn: the reflected / refracted rays of every hit of generation `gen` (src/world.rs:68-102) and the
+// Schlick reflectance (src/computation.rs:20-33), with n1 / n2 looked up first for hits on transparent
+// shapes.  Launched while rays may still be spawned (remaining > 0); the deepest generation has no
+// children and k_combine is told so.
 // ------------------------------------------------------------------------------------------------
 template <class R, bool COUNT, bool PACKET>
-__global__ void __launch_bounds__(256) k_shade(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch) {
+__global__ void __launch_bounds__(256) k_spawn(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int any_transparent, int launch) {
+  __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
+  int* lds = PACKET ? lds_stack + (threadIdx.x >> 6) * STACK_DEPTH : lds_stack + threadIdx.x;
+  Work wk;
   uint32_t start, gcount;
   gen_range(ctl, gen, pool.capacity, start, gcount);
   const uint32_t child_start = start + gcount;
   const uint32_t wave = threadIdx.x >> 6;
-  __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
   __shared__ uint32_t s_cnt[BLOCK / 64];
-  int* lds = PACKET ? lds_stack + (threadIdx.x >> 6) * STACK_DEPTH : lds_stack + threadIdx.x;
-  Work wk;
-  // block-uniform trip count: every wave reaches the barriers, all 64 lanes stay converged for ballots
+  // block-uniform trip count: every wave reaches the barriers
   for (uint32_t rbase = blockIdx.x * BLOCK; rbase < gcount; rbase += gridDim.x * BLOCK) {
     const uint32_t i = rbase + threadIdx.x;
     const uint32_t r = start + (i < gcount ? i : 0u);
@@ -893,39 +950,21 @@ __global__ void __launch_bounds__(256) k_shade(DevScene<R> sc, RayPool<R> pool, 
     if (__syncthreads_or(valid) == 0) continue;  // block-uniform
     const int p = valid ? p_raw : 0;
     const PrimInfo info = sc.prim_info[p];
-
-    // is_shadowed(over_point)
-    bool shadowed;
-    {
-      V3<R> over_point = {R(0), R(0), R(0)};
-      if (valid) over_point = prepare(sc, pool, r, p, info.flags).over_point;
-      const V3<R> lv = ld3(sc.light_pos) - over_point;
-      const R distance = sqrt(dot(lv, lv));
-      const V3<R> ldir = {lv.x / distance, lv.y / distance, lv.z / distance};
-      AnyVis<R, COUNT> av(sc, over_point, ldir, distance + eps<R>(), wk);
-      if constexpr (PACKET) {
-        traverse_packet<R, COUNT>(sc, over_point, ldir, valid, av, wk, lds);
-      } else {
-        if (valid) traverse<R, COUNT>(sc, over_point, ldir, av, wk, lds);
-      }
-      shadowed = av.found;
+    const bool slot_r = valid && (info.flags & PF_REFLECTIVE);
+    const bool slot_t = valid && (info.flags & PF_TRANSPARENT);
+    R n1 = R(1), n2 = R(1);
+    if (any_transparent && __ballot(slot_t) != 0ull) {  // wave-uniform
+      const V3<R> o = ld3(pool.org + 3ull * r), d = ld3(pool.dir + 3ull * r);
+      container_indices<R, COUNT, PACKET>(sc, slot_t, p, info, o, d, pool.hit_t[r], lds, wk, n1, n2);
     }
-
-    // children.  The ray id goes through an opaque move so that nothing of the first prepare() is kept
-    // alive in registers across the traversal.
-    uint32_t r2 = r;
-    asm volatile("" : "+v"(r2));
-    const bool slot_r = valid && remaining > 0 && (info.flags & PF_REFLECTIVE);
-    const bool slot_t = valid && remaining > 0 && (info.flags & PF_TRANSPARENT);
     bool want_refr = false;
     V3<R> refl_o = {R(0), R(0), R(0)}, refl_d = refl_o, refr_o = refl_o, refr_d = refl_o;
     R rs = R(-1);
     if (slot_r || slot_t) {
-      const Prepared<R> c = prepare(sc, pool, r2, p, info.flags);
+      const Prepared<R> c = prepare(sc, pool, r, p, info.flags);
       refl_o = c.over_point;
       refl_d = reflect(c.d, c.normalv_temp);  // un-flipped normal (src/intersection.rs:85)
       if (slot_t) {
-        const R n1 = pool.n12[2ull * r2], n2 = pool.n12[2ull * r2 + 1];
         const R n_ratio = n1 / n2;
         const R cos_ti = dot(c.eyev, c.normalv);
         const R sin2_t = n_ratio * n_ratio * (R(1) - cos_ti * cos_ti);
@@ -996,7 +1035,6 @@ __global__ void __launch_bounds__(256) k_shade(DevScene<R> sc, RayPool<R> pool, 
       pool.child[2ull * r] = child_r;
       pool.child[2ull * r + 1] = child_t;
       pool.mixr[r] = rs;
-      pool.shadow[r] = shadowed ? 1 : 0;
     }
   }
   flush_work<COUNT>(ctl, launch, wk);
@@ -1005,7 +1043,8 @@ __global__ void __launch_bounds__(256) k_shade(DevScene<R> sc, RayPool<R> pool, 
 // ------------------------------------------------------------------------------------------------
 // k_combine: Material::lighting (src/material.rs:108-162) and shade_hit's sum (src/world.rs:117-126) for
 // every hit of generation `gen`; runs from the deepest generation back to 0, so the children's colours
-// are final when their parent adds them.  Generation 0 may write the canvas directly.
+// are final when their parent adds them.  Generation 0 may write the canvas directly.  `has_children` is 0
+// for the deepest generation, whose rays spawned nothing (remaining == 0: src/world.rs:69, :79).
 // ------------------------------------------------------------------------------------------------
 enum OutMode { OUT_NONE = -1, OUT_LINEAR = 0, OUT_ROWMAJOR = 1, OUT_TILES = 2 };
 
@@ -1028,7 +1067,7 @@ RT_FN void write_pixel(const DevCamera<R>& cam, uint32_t i, int mode, float* out
 }
 
 template <class R>
-__global__ void __launch_bounds__(256) k_combine(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, DevCamera<R> cam, int mode, float* out) {
+__global__ void __launch_bounds__(256) k_combine(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int has_children, DevCamera<R> cam, int mode, float* out) {
   uint32_t start, gcount;
   gen_range(ctl, gen, pool.capacity, start, gcount);
   for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < gcount; i += gridDim.x * BLOCK) {
@@ -1040,8 +1079,9 @@ __global__ void __launch_bounds__(256) k_combine(DevScene<R> sc, RayPool<R> pool
       const DevMaterial<R>& m = sc.materials[info.flags >> PF_MAT_SHIFT];
       const Prepared<R> pc = prepare(sc, pool, r, p, info.flags);
       const V3<R> surface = lighting(sc, m, pc.over_point, pc.eyev, pc.normalv, pool.shadow[r] != 0);
-      const int32_t cr = pool.child[2ull * r], ct = pool.child[2ull * r + 1];
-      const R rs = pool.mixr[r];
+      int32_t cr = -1, ct = -1;
+      R rs = R(-1);
+      if (has_children) cr = pool.child[2ull * r], ct = pool.child[2ull * r + 1], rs = pool.mixr[r];
       V3<R> refl = {R(0), R(0), R(0)}, refr = {R(0), R(0), R(0)};
       if (cr >= 0) refl = ld3(pool.color + 3ull * cr) * m.reflective;
       if (ct >= 0) refr = ld3(pool.color + 3ull * ct) * m.transparency;

@@ -66,13 +66,15 @@ struct rt355_ctx {
   int device = 0;
   int real_bits = 64;
   hipStream_t stream = nullptr;
+  hipStream_t side = nullptr;  // shadow launches, beside the trace / spawn chain
+  hipEvent_t ev_traced[RT355_MAX_GEN], ev_side_done;
   double pool_factor = 8.0;
   bool counting = false, timing = false;
   int exact_cones = 0;
   int packet_gens = 2;  // generations 0..packet_gens-1 use the wave-packet traversal
-  DevBuf org, dir, hit_t, hit_uv, hit_prim, color, mixr, n12, shadow, child, blk_hits, blk_children, blk_base, ctl, io_in, io_out, io_out2;
+  DevBuf org, dir, hit_t, hit_uv, hit_prim, color, mixr, shadow, child, blk_hits, blk_children, blk_base, ctl, io_in, io_out, io_out2;
   hipEvent_t ev[RT355_MAX_LAUNCH + 1];
-  bool ev_ok = false;
+  bool ev_ok = false, side_ok = false;
   int n_cu = 256;
 };
 
@@ -83,6 +85,7 @@ struct rt355_scene {
   int32_t n_nodes = 0, n_bounded = 0, n_prims = 0, n_materials = 0, max_depth = 0;
   bool any_secondary = false, any_transparent = false;
   float light_pos[3], light_int[3];
+  float box_abs_max = 0.f;
   size_t device_bytes = 0;
 };
 
@@ -98,6 +101,7 @@ DevScene<R> dev_scene(const rt355_scene* s) {
   d.trin = (const DevTriNormals<R>*)s->trin.p;
   d.materials = (const DevMaterial<R>*)s->materials.p;
   d.n_nodes = s->n_nodes, d.n_bounded = s->n_bounded, d.n_prims = s->n_prims, d.n_materials = s->n_materials;
+  d.box_abs_max = s->box_abs_max;
   for (int k = 0; k < 3; ++k) d.light_pos[k] = R(s->light_pos[k]), d.light_int[k] = R(s->light_int[k]);
   return d;
 }
@@ -158,7 +162,6 @@ int ensure_pool(rt355_ctx* c, uint64_t n_primary, bool secondary, RayPool<R>& po
   if ((rc = c->hit_prim.ensure(cap * sizeof(int32_t)))) return rc;
   if ((rc = c->color.ensure(cap * 3 * sizeof(R)))) return rc;
   if ((rc = c->mixr.ensure(cap * sizeof(R)))) return rc;
-  if ((rc = c->n12.ensure(cap * 2 * sizeof(R)))) return rc;
   if ((rc = c->shadow.ensure(cap))) return rc;
   if ((rc = c->child.ensure(cap * 2 * sizeof(int32_t)))) return rc;
   const uint64_t nblk = cap / BLOCK + 2;
@@ -168,7 +171,7 @@ int ensure_pool(rt355_ctx* c, uint64_t n_primary, bool secondary, RayPool<R>& po
   if ((rc = c->ctl.ensure(sizeof(FrameCtl)))) return rc;
   pool.org = (R*)c->org.p, pool.dir = (R*)c->dir.p, pool.hit_t = (R*)c->hit_t.p, pool.hit_uv = (R*)c->hit_uv.p;
   pool.hit_prim = (int32_t*)c->hit_prim.p, pool.color = (R*)c->color.p, pool.mixr = (R*)c->mixr.p;
-  pool.n12 = (R*)c->n12.p, pool.shadow = (uint8_t*)c->shadow.p;
+  pool.shadow = (uint8_t*)c->shadow.p;
   pool.child = (int32_t*)c->child.p;
   pool.blk_hits = (uint32_t*)c->blk_hits.p, pool.blk_children = (uint32_t*)c->blk_children.p, pool.blk_base = (uint32_t*)c->blk_base.p;
   pool.capacity = (int64_t)cap;
@@ -200,6 +203,9 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, uint32
     if (log.n < RT355_MAX_LAUNCH) log.kind[log.n] = kind, log.gen[log.n] = gen;
     return RT355_OK;
   };
+  // Shadow rays feed nothing but k_combine, so they leave the critical path: with per-launch timing or
+  // counting off they run on the side stream, each generation as soon as its trace has finished.
+  const bool overlap = !c->timing && !COUNT;
   for (int g = 0; g <= depth; ++g) {
     // generation g > 0 can hold at most twice the hits of g-1; its size is only known on the device
     const uint32_t grid = g == 0 ? grid0 : std::min<uint32_t>(grid_cap, (uint32_t)((pool.capacity + BLOCK - 1) / BLOCK));
@@ -210,28 +216,47 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, uint32
       hipLaunchKernelGGL((k_trace<R, COUNT, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n);
     else
       hipLaunchKernelGGL((k_trace<R, COUNT, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, pool.blk_hits, pool.blk_children, pool.blk_base, ctl, g, (long long)pool.capacity);
     log.n++;
-    if (s->any_transparent && g < depth) {  // n1 / n2 only matter while rays can still be spawned
-      if ((rc = rec(RT355_K_CONTAINER, g))) return rc;
-      if (packet)
-        hipLaunchKernelGGL((k_container<R, COUNT, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, log.n);
-      else
-        hipLaunchKernelGGL((k_container<R, COUNT, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, log.n);
-      log.n++;
+    hipStream_t shadow_stream = c->stream;
+    if (overlap) {
+      HIP_TRY(hipEventRecord(c->ev_traced[g], c->stream));
+      HIP_TRY(hipStreamWaitEvent(c->side, c->ev_traced[g], 0));
+      shadow_stream = c->side;
     }
-    if ((rc = rec(RT355_K_SHADE, g))) return rc;
-    if (packet)
-      hipLaunchKernelGGL((k_shade<R, COUNT, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n);
-    else
-      hipLaunchKernelGGL((k_shade<R, COUNT, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n);
-    log.n++;
+    auto shadow = [&]() {
+      int rc2;
+      if ((rc2 = rec(RT355_K_SHADE, g))) return rc2;
+      if (packet)
+        hipLaunchKernelGGL((k_shadow<R, COUNT, true>), dim3(grid), dim3(block), 0, shadow_stream, sc, pool, ctl, g, log.n);
+      else
+        hipLaunchKernelGGL((k_shadow<R, COUNT, false>), dim3(grid), dim3(block), 0, shadow_stream, sc, pool, ctl, g, log.n);
+      log.n++;
+      return (int)RT355_OK;
+    };
+    if (overlap && (rc = shadow())) return rc;
+    if (g < depth) {
+      hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, pool.blk_hits, pool.blk_children, pool.blk_base, ctl, g, (long long)pool.capacity);
+      if ((rc = rec(RT355_K_SPAWN, g))) return rc;
+      if (packet)
+        hipLaunchKernelGGL((k_spawn<R, COUNT, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, s->any_transparent ? 1 : 0, log.n);
+      else
+        hipLaunchKernelGGL((k_spawn<R, COUNT, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, s->any_transparent ? 1 : 0, log.n);
+      log.n++;
+    } else {
+      // the deepest generation spawns nothing; the scan still totals its hits
+      hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, pool.blk_hits, pool.blk_children, pool.blk_base, ctl, g, (long long)pool.capacity);
+    }
+    if (!overlap && (rc = shadow())) return rc;
+  }
+  if (overlap) {
+    HIP_TRY(hipEventRecord(c->ev_side_done, c->side));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_side_done, 0));
   }
   for (int g = depth; g >= 0; --g) {
     const uint32_t grid = g == 0 ? grid0 : std::min<uint32_t>(grid_cap, (uint32_t)((pool.capacity + BLOCK - 1) / BLOCK));
     int rc;
     if ((rc = rec(RT355_K_COMBINE, g))) return rc;
-    hipLaunchKernelGGL((k_combine<R>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, cam, out_mode, out_dev);
+    hipLaunchKernelGGL((k_combine<R>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, g < depth ? 1 : 0, cam, out_mode, out_dev);
     log.n++;
   }
   if (c->timing && log.n <= RT355_MAX_LAUNCH) HIP_TRY(hipEventRecord(c->ev[log.n], c->stream));
@@ -274,10 +299,8 @@ int finish_stats(rt355_ctx* c, const LaunchLog& log, double frame_ms, rt355_stat
       st->launch_max_box_tests[i] = w[10];
       st->launch_max_wave_clocks[i] = w[11];
       const int g = log.gen[i];
-      if (log.kind[i] == RT355_K_SHADE) {
-        // precompute for the shadow ray + spawned children (every ray of generation g+1)
-        fl += F_PREPARE * (double)hits_of[g] + 0.5 * (F_REFLECT + F_REFRACT) * (double)h.gen_count[g + 1].v;
-      }
+      if (log.kind[i] == RT355_K_SHADE) fl += F_PREPARE * (double)hits_of[g];  // over_point of every hit
+      if (log.kind[i] == RT355_K_SPAWN) fl += 0.5 * (F_REFLECT + F_REFRACT) * (double)h.gen_count[g + 1].v;
       if (log.kind[i] == RT355_K_COMBINE) fl += F_SHADE * (double)hits_of[g];
       st->launch_flops[i] = fl;
     }
@@ -381,6 +404,10 @@ int upload_impl(rt355_ctx* c, const HostScene& hs, rt355_scene* s) {
     }
     nodes[i].c0 = hs.nodes[i].c0, nodes[i].c1 = hs.nodes[i].c1, nodes[i].pad0 = nodes[i].pad1 = 0;
   }
+  s->box_abs_max = 0.f;
+  if (nn)  // node 0 is the root: its two boxes enclose every other
+    for (int k = 0; k < 3; ++k)
+      for (float v : {nodes[0].lo0[k], nodes[0].hi0[k], nodes[0].lo1[k], nodes[0].hi1[k]}) s->box_abs_max = std::max(s->box_abs_max, std::fabs(v));
   std::vector<PrimInfo> info(np);
   std::vector<DevXform<R>> xf(np);
   bool any_tri = false;
@@ -467,6 +494,14 @@ int rt355_ctx_create(rt355_ctx** out, int device_id, int real_bits) {
       return set_err(RT355_EHIP, "hipEventCreate failed");
     }
   c->ev_ok = true;
+  bool side_ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; i < RT355_MAX_GEN && side_ok; ++i) side_ok = hipEventCreateWithFlags(&c->ev_traced[i], hipEventDisableTiming) == hipSuccess;
+  side_ok = side_ok && hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming) == hipSuccess;
+  if (!side_ok) {
+    delete c;  // the process keeps whatever was created; this only happens when the runtime is unusable
+    return set_err(RT355_EHIP, "side stream / event creation failed");
+  }
+  c->side_ok = true;
   if (const char* e = getenv("RT355_PACKET_GENS")) c->packet_gens = atoi(e);
   *out = c;
   return RT355_OK;
@@ -476,9 +511,15 @@ void rt355_ctx_destroy(rt355_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (DevBuf* b : {&c->org, &c->dir, &c->hit_t, &c->hit_uv, &c->hit_prim, &c->color, &c->mixr, &c->n12, &c->shadow, &c->child, &c->blk_hits, &c->blk_children, &c->blk_base, &c->ctl, &c->io_in, &c->io_out, &c->io_out2}) b->release();
+  if (c->side) (void)hipStreamSynchronize(c->side);
+  for (DevBuf* b : {&c->org, &c->dir, &c->hit_t, &c->hit_uv, &c->hit_prim, &c->color, &c->mixr, &c->shadow, &c->child, &c->blk_hits, &c->blk_children, &c->blk_base, &c->ctl, &c->io_in, &c->io_out, &c->io_out2}) b->release();
   if (c->ev_ok)
     for (int i = 0; i <= RT355_MAX_LAUNCH; ++i) (void)hipEventDestroy(c->ev[i]);
+  if (c->side_ok) {
+    for (int i = 0; i < RT355_MAX_GEN; ++i) (void)hipEventDestroy(c->ev_traced[i]);
+    (void)hipEventDestroy(c->ev_side_done);
+  }
+  if (c->side) (void)hipStreamDestroy(c->side);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }

@@ -85,6 +85,7 @@ struct DevScene {
   const DevTriNormals<R>* trin;   // n_prims (valid for triangle kinds)
   const DevMaterial<R>* materials;
   int32_t n_nodes, n_bounded, n_prims, n_materials;
+  float box_abs_max;  // largest |coordinate| of any BVH box: scales the error bound of the slab test
   R light_pos[3], light_int[3];
 };
 
@@ -107,12 +108,11 @@ struct RayPool {
   int32_t* hit_prim;   // prim id, -1 = miss
   R* color;    // 3 per ray: colour of the ray (color_at), written by the combine pass
   R* mixr;     // schlick reflectance of the hit (< 0: plain sum)
-  R* n12;      // 2 per ray: n1, n2 of a hit on a transparent shape
   int32_t* child;      // 2 per ray: reflected, refracted child ray id (-1 = none)
   uint8_t* shadow;     // is_shadowed(over_point) of the hit
   // Child-ray slots are handed out without atomics: k_trace leaves, per block of BLOCK rays, the number of
   // hits and an upper bound of the children they can spawn; k_scan turns the bounds into exclusive
-  // prefixes; k_shade places its children at prefix + rank inside the block.
+  // prefixes; k_spawn places its children at prefix + rank inside the block.
   uint32_t* blk_hits;
   uint32_t* blk_children;
   uint32_t* blk_base;

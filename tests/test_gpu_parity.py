@@ -347,3 +347,31 @@ def test_counting_mode_reports_work(dev):
     assert kinds[:2] == [_abi.K_TRACE, _abi.K_SHADE]
     assert st.launch_box_tests[0] > 0 and st.launch_prim_tests[0] > 0 and st.launch_flops[0] > 0
     assert all(st.launch_ms[i] >= 0 for i in range(st.n_launch))
+
+
+def test_deepest_recursion_with_instrumentation(dev, oracle):
+    """max_depth 7 is the limit of the interface: every generation, with and without per-launch
+    instrumentation (which also moves the shadow launches from the side stream to the main one)."""
+    world, cam = scenes.glass(64, 48)
+    scene = dev.upload(world)
+    plain = scene.render(cam, 7).pixels.copy()
+    dev.set_counting(True)
+    dev.set_timing(True)
+    st = Stats()
+    try:
+        inst = scene.render(cam, 7, st).pixels.copy()
+    finally:
+        dev.set_counting(False)
+        dev.set_timing(False)
+    scene.close()
+    assert np.array_equal(plain, inst)
+    assert st.n_launch <= _abi.RT355_MAX_LAUNCH
+    kinds = list(st.launch_kind[: st.n_launch])
+    assert kinds.count(_abi.K_TRACE) == 8 and kinds.count(_abi.K_SPAWN) == 7 and kinds.count(_abi.K_COMBINE) == 8
+    want, cnt, _ = oracle.render(world, cam, 7, dev.real_bits, threads=8)
+    frac = mismatch(oracle.to_u8(plain), oracle.to_u8(want))
+    assert frac <= (0.004 if dev.real_bits == 64 else 0.02)
+    tot_o = int(cnt["radiance"].sum())
+    dev_radiance = int(st.total_radiance) - int(st.radiance_rays[0]) + 64 * 48  # generation 0 includes tile padding
+    assert abs(dev_radiance - tot_o) <= max(8, 0.03 * tot_o)
+    assert abs(int(st.total_shadow) - int(cnt["hits"].sum())) <= max(8, 0.03 * tot_o)
