@@ -297,23 +297,33 @@ RT_FN void traverse(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work& wk,
   int cur = 0;
   for (;;) {
     if (cur >= 0) {
-      const BvhNode<float> N = sc.nodes[cur];
-      float tlo, thi, an, bn;
+      const BvhNode4 N = sc.nodes[cur];
+      float tlo, thi;
       slab_interval(vis.tmin(), vis.tmax(), tlo, thi);
-      const bool ha = slab_test(sr, N.lo0[0], N.lo0[1], N.lo0[2], N.hi0[0], N.hi0[1], N.hi0[2], tlo, thi, an);
-      const bool hb = slab_test(sr, N.lo1[0], N.lo1[1], N.lo1[2], N.hi1[0], N.hi1[1], N.hi1[2], tlo, thi, bn);
-      const int c0 = N.c0, c1 = N.c1;
-      if constexpr (COUNT) wk.box += 2;
-      if (ha && hb) {
-        const bool a_first = an <= bn;
-        const int far = a_first ? c1 : c0;
-        if (sp < LDS_STACK) lds[sp * BLOCK] = far; else spill[sp - LDS_STACK] = far;
+      // entry parameter of every child the ray may touch, +inf for the others
+      float k0, k1, k2, k3;
+      if (!slab_test(sr, N.box[0][0], N.box[0][1], N.box[0][2], N.box[0][3], N.box[0][4], N.box[0][5], tlo, thi, k0)) k0 = INFINITY;
+      if (!slab_test(sr, N.box[1][0], N.box[1][1], N.box[1][2], N.box[1][3], N.box[1][4], N.box[1][5], tlo, thi, k1)) k1 = INFINITY;
+      if (!slab_test(sr, N.box[2][0], N.box[2][1], N.box[2][2], N.box[2][3], N.box[2][4], N.box[2][5], tlo, thi, k2)) k2 = INFINITY;
+      if (!slab_test(sr, N.box[3][0], N.box[3][1], N.box[3][2], N.box[3][3], N.box[3][4], N.box[3][5], tlo, thi, k3)) k3 = INFINITY;
+      int c0 = N.c[0], c1 = N.c[1], c2 = N.c[2], c3 = N.c[3];
+      if constexpr (COUNT) wk.box += (c0 != -1) + (c1 != -1) + (c2 != -1) + (c3 != -1);
+      // nearest first: 5-exchange sorting network on (entry, child)
+      auto order = [](float& ka, int& ca, float& kb, int& cb) {
+        const bool sw = kb < ka;
+        const float kt = sw ? kb : ka, ku = sw ? ka : kb;
+        const int ct = sw ? cb : ca, cu = sw ? ca : cb;
+        ka = kt, kb = ku, ca = ct, cb = cu;
+      };
+      order(k0, c0, k1, c1), order(k2, c2, k3, c3), order(k0, c0, k2, c2), order(k1, c1, k3, c3), order(k1, c1, k2, c2);
+      auto push = [&](int child) {
+        if (sp < LDS_STACK) lds[sp * BLOCK] = child; else spill[sp - LDS_STACK] = child;
         ++sp;
-        cur = a_first ? c0 : c1;
-        continue;
-      }
-      if (ha) { cur = c0; continue; }
-      if (hb) { cur = c1; continue; }
+      };
+      if (k3 < INFINITY) push(c3);
+      if (k2 < INFINITY) push(c2);
+      if (k1 < INFINITY) push(c1);
+      if (k0 < INFINITY) { cur = c0; continue; }
     } else
     {
       const uint32_t leaf = (uint32_t)~cur;
@@ -348,9 +358,8 @@ RT_FN void traverse(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work& wk,
 // ------------------------------------------------------------------------------------------------
 // Packet traversal: the 64 rays of a wave walk the BVH TOGETHER.  The current node, the stack and every
 // branch are wave-uniform, so node and triangle records come in through scalar loads (one request per
-// wave instead of 64 divergent 112-byte fetches) and the vector ALU does nothing but slab and triangle
-// arithmetic.  A child is entered when ANY live lane's ray overlaps its box; the near child is the one
-// most lanes want first.  Every lane tests every triangle of a visited leaf against its own interval, so
+// wave instead of 64 divergent 128-byte fetches) and the vector ALU does nothing but slab and triangle
+// arithmetic.  A child is entered when ANY live lane's ray overlaps its box.  Every lane tests every triangle of a visited leaf against its own interval, so
 // each lane still finds exactly its own nearest / any hit.  Good for coherent rays (primary, shadow,
 // mirror reflections); incoherent generations use the per-lane traverse above.
 // All 64 lanes must call this together; `live` is false for lanes without a ray.
@@ -379,24 +388,41 @@ RT_FN void traverse_packet(const DevScene<R>& sc, V3<R> o, V3<R> d, bool live, V
   for (;;) {
     if (__ballot(live) == 0ull) return;
     if (cur >= 0) {
-      cptr<float> q = (cptr<float>)(const float*)&sc.nodes[cur];
-      cptr<int32_t> qc = (cptr<int32_t>)(const int32_t*)&sc.nodes[cur].c0;
-      const int c0 = qc[0], c1 = qc[1];
-      float tlo, thi, an, bn;
+      cptr<float> q = (cptr<float>)(const float*)&sc.nodes[cur].box[0][0];
+      cptr<int32_t> qc = (cptr<int32_t>)(const int32_t*)&sc.nodes[cur].c[0];
+      float tlo, thi;
       slab_interval(vis.tmin(), vis.tmax(), tlo, thi);
-      const bool ha = slab_test(sr, q[0], q[1], q[2], q[3], q[4], q[5], tlo, thi, an) && live;
-      const bool hb = slab_test(sr, q[6], q[7], q[8], q[9], q[10], q[11], tlo, thi, bn) && live;
-      if constexpr (COUNT) wk.box += live ? 2 : 0;
-      const unsigned long long ua = __ballot(ha), ub = __ballot(hb);
-      if (ua && ub) {
-        const bool a_first = __popcll(__ballot(ha && (!hb || an <= bn))) >= __popcll(__ballot(hb && (!ha || bn < an)));
-        const int far = a_first ? c1 : c0;
-        wstack[sp++] = far;
-        cur = a_first ? c0 : c1;
-        continue;
+      // A child is entered when any live lane may touch it.  Order: by the entry parameter of the first
+      // lane that touches the child (a scalar, so the sort runs on the scalar unit).
+      uint32_t key[BVH_WIDTH];
+      int ch[BVH_WIDTH];
+      int n_valid = 0;
+#pragma unroll
+      for (int k = 0; k < BVH_WIDTH; ++k) {
+        float tn;
+        const bool h = slab_test(sr, q[6 * k], q[6 * k + 1], q[6 * k + 2], q[6 * k + 3], q[6 * k + 4], q[6 * k + 5], tlo, thi, tn) && live;
+        const unsigned long long m = __ballot(h);
+        ch[k] = qc[k];
+        n_valid += ch[k] != -1;
+        key[k] = 0xFFFFFFFFu;
+        if (m) {
+          const int lane = __ffsll((long long)m) - 1;
+          key[k] = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(fmaxf(tn, 0.f)), lane);
+        }
       }
-      if (ua) { cur = c0; continue; }
-      if (ub) { cur = c1; continue; }
+      if constexpr (COUNT) wk.box += live ? n_valid : 0;
+      auto order = [](uint32_t& ka, int& ca, uint32_t& kb, int& cb) {
+        if (kb < ka) {
+          const uint32_t kt = ka; ka = kb, kb = kt;
+          const int ct = ca; ca = cb, cb = ct;
+        }
+      };
+      order(key[0], ch[0], key[1], ch[1]), order(key[2], ch[2], key[3], ch[3]), order(key[0], ch[0], key[2], ch[2]);
+      order(key[1], ch[1], key[3], ch[3]), order(key[1], ch[1], key[2], ch[2]);
+      if (key[3] != 0xFFFFFFFFu) wstack[sp++] = ch[3];
+      if (key[2] != 0xFFFFFFFFu) wstack[sp++] = ch[2];
+      if (key[1] != 0xFFFFFFFFu) wstack[sp++] = ch[1];
+      if (key[0] != 0xFFFFFFFFu) { cur = ch[0]; continue; }
     } else {
       const uint32_t leaf = (uint32_t)~cur;
       const int first = (int)(leaf & LEAF_FIRST_MASK), count = (int)(leaf >> 26);
@@ -642,6 +668,15 @@ __global__ void __launch_bounds__(256) k_trace(DevScene<R> sc, RayPool<R> pool, 
     __syncthreads();
   }
   flush_work<COUNT>(ctl, launch, wk);
+}
+
+// Frame control block back to zero, generation 0 sized: a launch instead of a host-to-device copy, which
+// from pageable memory would stall the host for longer than a small frame takes to render.
+__global__ void __launch_bounds__(256) k_reset_ctl(FrameCtl* ctl, uint32_t n_primary) {
+  uint32_t* w = (uint32_t*)ctl;
+  for (uint32_t i = threadIdx.x; i < sizeof(FrameCtl) / 4; i += blockDim.x) w[i] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) ctl->gen_count[0].v = n_primary;
 }
 
 // ------------------------------------------------------------------------------------------------

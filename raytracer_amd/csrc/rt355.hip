@@ -75,6 +75,7 @@ struct rt355_ctx {
   DevBuf org, dir, hit_t, hit_uv, hit_prim, color, mixr, shadow, child, blk_hits, blk_children, blk_base, ctl, io_in, io_out, io_out2;
   hipEvent_t ev[RT355_MAX_LAUNCH + 1];
   bool ev_ok = false, side_ok = false;
+  FrameCtl* ctl_host = nullptr;  // pinned
   int n_cu = 256;
 };
 
@@ -94,7 +95,7 @@ namespace {
 template <class R>
 DevScene<R> dev_scene(const rt355_scene* s) {
   DevScene<R> d;
-  d.nodes = (const BvhNode<float>*)s->nodes.p;
+  d.nodes = (const BvhNode4*)s->nodes.p;
   d.prim_info = (const PrimInfo*)s->prim_info.p;
   d.xform = (const DevXform<R>*)s->xform.p;
   d.tri = (const DevTri*)s->tri.p;
@@ -190,10 +191,7 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, uint32
                     int out_mode, float* out_dev, LaunchLog& log) {
   DevScene<R> sc = dev_scene<R>(s);
   FrameCtl* ctl = (FrameCtl*)c->ctl.p;
-  FrameCtl init;
-  memset(&init, 0, sizeof(init));
-  init.gen_count[0].v = n_primary;
-  HIP_TRY(hipMemcpyAsync(ctl, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_reset_ctl, dim3(1), dim3(256), 0, c->stream, ctl, n_primary);
   const int depth = s->any_secondary ? max_depth : 0;  // no reflective / transparent material: one generation
   const int block = BLOCK;
   const uint32_t grid0 = (n_primary + BLOCK - 1) / BLOCK;  // one block per 256 rays
@@ -260,14 +258,16 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, uint32
     log.n++;
   }
   if (c->timing && log.n <= RT355_MAX_LAUNCH) HIP_TRY(hipEventRecord(c->ev[log.n], c->stream));
+  // counters and the overflow flag travel to pinned host memory behind the last kernel: the caller's one
+  // stream synchronisation makes them readable
+  HIP_TRY(hipMemcpyAsync(c->ctl_host, ctl, sizeof(FrameCtl), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipGetLastError());
   return RT355_OK;
 }
 
+// After the stream has been synchronised behind run_generations.
 int finish_stats(rt355_ctx* c, const LaunchLog& log, double frame_ms, rt355_stats* st, bool* overflow) {
-  FrameCtl h;
-  HIP_TRY(hipMemcpyAsync(&h, c->ctl.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  const FrameCtl& h = *c->ctl_host;
   *overflow = h.overflow.v != 0;
   if (!st) return RT355_OK;
   memset(st, 0, sizeof(*st));
@@ -357,10 +357,7 @@ int rays_impl(rt355_ctx* c, const rt355_scene* s, const float* rays_host, size_t
   bool overflow = false;
   if (trace_only) {
     DevScene<R> sc = dev_scene<R>(s);
-    FrameCtl init;
-    memset(&init, 0, sizeof(init));
-    init.gen_count[0].v = (uint32_t)n;
-    HIP_TRY(hipMemcpyAsync(c->ctl.p, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_reset_ctl, dim3(1), dim3(256), 0, c->stream, (FrameCtl*)c->ctl.p, (uint32_t)n);
     hipLaunchKernelGGL((k_trace<R, false, false>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (FrameCtl*)c->ctl.p, 0, 0, 0);
     if ((rc = c->io_out.ensure(n * sizeof(double)))) return rc;
     if ((rc = c->io_out2.ensure(n * sizeof(int32_t)))) return rc;
@@ -392,22 +389,23 @@ int rays_impl(rt355_ctx* c, const rt355_scene* s, const float* rays_host, size_t
 template <class R>
 int upload_impl(rt355_ctx* c, const HostScene& hs, rt355_scene* s) {
   const size_t np = hs.prims.size(), nn = hs.nodes.size(), nm = hs.materials.size();
-  using NR = float;
-  std::vector<BvhNode<NR>> nodes(nn);
-  for (size_t i = 0; i < nn; ++i) {
-    for (int k = 0; k < 3; ++k) {
-      // boxes were padded in double; when narrowing to float round outward
-      auto down = [](double v) { NR r = (NR)v; if ((double)r > v) r = std::nextafter(r, -std::numeric_limits<NR>::infinity()); return r; };
-      auto up = [](double v) { NR r = (NR)v; if ((double)r < v) r = std::nextafter(r, std::numeric_limits<NR>::infinity()); return r; };
-      nodes[i].lo0[k] = down(hs.nodes[i].lo0[k]), nodes[i].hi0[k] = up(hs.nodes[i].hi0[k]);
-      nodes[i].lo1[k] = down(hs.nodes[i].lo1[k]), nodes[i].hi1[k] = up(hs.nodes[i].hi1[k]);
-    }
-    nodes[i].c0 = hs.nodes[i].c0, nodes[i].c1 = hs.nodes[i].c1, nodes[i].pad0 = nodes[i].pad1 = 0;
-  }
+  std::vector<BvhNode4> nodes(nn);
   s->box_abs_max = 0.f;
-  if (nn)  // node 0 is the root: its two boxes enclose every other
-    for (int k = 0; k < 3; ++k)
-      for (float v : {nodes[0].lo0[k], nodes[0].hi0[k], nodes[0].lo1[k], nodes[0].hi1[k]}) s->box_abs_max = std::max(s->box_abs_max, std::fabs(v));
+  for (size_t i = 0; i < nn; ++i) {
+    // boxes were padded in double; when narrowing to float round outward
+    auto down = [](double v) { float r = (float)v; if ((double)r > v) r = std::nextafter(r, -std::numeric_limits<float>::infinity()); return r; };
+    auto up = [](double v) { float r = (float)v; if ((double)r < v) r = std::nextafter(r, std::numeric_limits<float>::infinity()); return r; };
+    for (int k = 0; k < BVH_WIDTH; ++k) {
+      for (int a = 0; a < 3; ++a) {
+        nodes[i].box[k][a] = down(hs.nodes[i].lo[k][a]), nodes[i].box[k][3 + a] = up(hs.nodes[i].hi[k][a]);
+        if (i == 0)  // node 0 is the root: its boxes enclose every other
+          for (float v : {nodes[i].box[k][a], nodes[i].box[k][3 + a]})
+            if (std::isfinite(v)) s->box_abs_max = std::max(s->box_abs_max, std::fabs(v));
+      }
+      nodes[i].c[k] = hs.nodes[i].c[k];
+    }
+    for (int k = 0; k < 4; ++k) nodes[i].pad[k] = 0;
+  }
   std::vector<PrimInfo> info(np);
   std::vector<DevXform<R>> xf(np);
   bool any_tri = false;
@@ -448,7 +446,7 @@ int upload_impl(rt355_ctx* c, const HostScene& hs, rt355_scene* s) {
     return RT355_OK;
   };
   int rc;
-  if ((rc = put(s->nodes, nodes.data(), nn * sizeof(BvhNode<NR>)))) return rc;
+  if ((rc = put(s->nodes, nodes.data(), nn * sizeof(BvhNode4)))) return rc;
   if ((rc = put(s->prim_info, info.data(), np * sizeof(PrimInfo)))) return rc;
   if ((rc = put(s->xform, xf.data(), np * sizeof(DevXform<R>)))) return rc;
   if ((rc = put(s->tri, tri.data(), tri.size() * sizeof(DevTri)))) return rc;
@@ -502,6 +500,11 @@ int rt355_ctx_create(rt355_ctx** out, int device_id, int real_bits) {
     return set_err(RT355_EHIP, "side stream / event creation failed");
   }
   c->side_ok = true;
+  if (hipHostMalloc((void**)&c->ctl_host, sizeof(FrameCtl), hipHostMallocDefault) != hipSuccess) {
+    c->ctl_host = nullptr;
+    rt355_ctx_destroy(c);
+    return set_err(RT355_ENOMEM, "pinned host allocation failed");
+  }
   if (const char* e = getenv("RT355_PACKET_GENS")) c->packet_gens = atoi(e);
   *out = c;
   return RT355_OK;
@@ -521,6 +524,7 @@ void rt355_ctx_destroy(rt355_ctx* c) {
   }
   if (c->side) (void)hipStreamDestroy(c->side);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->ctl_host) (void)hipHostFree(c->ctl_host);
   delete c;
 }
 

@@ -3,7 +3,8 @@
 // Everything the kernels read is laid out here once, at scene upload:
 //   * prims: every non-Group shape, BVH leaf order first (bounded shapes), then the shapes that have no
 //     finite bound (planes, uncapped cylinders / cones).  A "prim id" p indexes all per-prim arrays.
-//   * nodes: binary BVH, each node carries BOTH child boxes so one fetch decides both descents.
+//   * nodes: 4-wide BVH, each node carries the boxes of ALL its children, so one fetch (one memory round
+//     trip, which is what a traversal step costs) decides up to four descents.
 //   * materials: deduplicated table (material.rs:6-17 + pattern.rs colours).
 #pragma once
 #include <stdint.h>
@@ -16,12 +17,13 @@ namespace rt355 {
 
 constexpr int TILE = 32;             // image tile edge; tile t belongs to rank t % n_ranks
 constexpr int TILE_PIX = TILE * TILE;
-constexpr int STACK_DEPTH = 64;      // traversal stack entries; the builder keeps the tree shallower
+constexpr int STACK_DEPTH = 64;      // traversal stack entries; the builder rejects trees that could need more
 constexpr int LDS_STACK = 24;        // of which this many live in LDS (one column per lane); the rest in scratch
 constexpr int BLOCK = 256;           // threads per block of the traversal kernels
 constexpr uint32_t LEAF_FIRST_MASK = 0x1FFFFFFu;  // leaf reference ~c: first | tri-only flag << 25 | count << 26
 constexpr uint32_t LEAF_TRI_BIT = 1u << 25;       // every prim of the leaf is a triangle with identity transform
-constexpr int MAX_TREE_DEPTH = 60;
+constexpr int MAX_TREE_DEPTH = 40;   // of the binary tree the builder collapses; a 4-wide node pushes up to 3 entries
+constexpr int BVH_WIDTH = 4;
 constexpr int LEAF_MAX = 4;
 constexpr int N_WORK_COUNTERS = 12;  // per launch: [0] box tests, [1] xforms, [2..10) prim tests per kind
 
@@ -38,12 +40,15 @@ struct PrimInfo {
   int32_t flags;  // kind | PF_* | material << PF_MAT_SHIFT
 };
 
-template <class R>
-struct alignas(16) BvhNode {
-  R lo0[3], hi0[3], lo1[3], hi1[3];
-  int32_t c0, c1;  // >= 0: inner node index; < 0: leaf reference, see LEAF_*
-  int32_t pad0, pad1;
+// One node of the 4-wide BVH, 128 bytes.  Boxes are stored in float, rounded outward, whatever the
+// arithmetic type of the intersection tests is.  Unused child slots hold an inverted box (lo = +inf,
+// hi = -inf), which no ray overlaps, and the empty leaf reference -1.
+struct alignas(16) BvhNode4 {
+  float box[BVH_WIDTH][6];   // per child: lo.xyz, hi.xyz
+  int32_t c[BVH_WIDTH];      // >= 0: inner node index; < 0: leaf reference, see LEAF_*
+  int32_t pad[4];
 };
+static_assert(sizeof(BvhNode4) == 128, "BvhNode4 layout");
 
 template <class R>
 struct DevMaterial {
@@ -77,8 +82,7 @@ struct DevTriNormals {  // smooth triangle: n1,n2,n3; flat triangle: nf (src/tri
 
 template <class R>
 struct DevScene {
-  const BvhNode<float>* nodes;    // n_nodes (0 when there is no bounded prim); boxes are stored in float,
-                                  // rounded outward, whatever R is: half the bytes per visit, same culling
+  const BvhNode4* nodes;          // n_nodes (0 when there is no bounded prim)
   const PrimInfo* prim_info;      // n_prims
   const DevXform<R>* xform;       // n_prims
   const DevTri* tri;              // n_prims (valid for triangle kinds)
@@ -149,15 +153,15 @@ struct HostPrim {
 };
 
 struct HostNode {
-  double lo0[3], hi0[3], lo1[3], hi1[3];
-  int32_t c0, c1;
+  double lo[BVH_WIDTH][3], hi[BVH_WIDTH][3];
+  int32_t c[BVH_WIDTH];
 };
 
 struct HostScene {
   std::vector<HostPrim> prims;  // final order: BVH leaf order, then the unbounded prims
   int32_t n_bounded = 0;
   std::vector<HostNode> nodes;
-  int32_t max_depth = 0;
+  int32_t max_depth = 0;  // most traversal-stack entries any descent can need
   std::vector<rt355_material> materials;
   bool any_secondary = false;    // some material is reflective or transparent
   bool any_transparent = false;  // some material is transparent

@@ -338,11 +338,12 @@ int build_host_scene(const rt355_shape_desc* shapes, size_t n, double pad_rel, i
     }
     B.nodes.reserve(2 * nb);
     int root = B.build(0, (int)nb, 0);
-    out.max_depth = B.max_depth + 1;
     // reorder prims into leaf order
     out.prims.reserve(nb + unbounded.size());
     for (size_t k = 0; k < nb; ++k) out.prims.push_back(bounded[B.order[k]]);
-    // emit device nodes in DFS order; every inner build node becomes one device node
+    // Collapse the binary tree into 4-wide nodes: a wide node starts from the two children of a binary
+    // inner node and keeps replacing its largest inner child by that child's two children until it has
+    // four, or only leaves.  Device nodes are emitted in DFS order.
     auto leaf_ref = [&](int first, int count) -> int32_t {
       bool tri_only = count > 0;
       for (int k = first; k < first + count; ++k) {
@@ -351,53 +352,70 @@ int build_host_scene(const rt355_shape_desc* shapes, size_t n, double pad_rel, i
       }
       return encode_leaf(first, count, tri_only);
     };
-    auto child_ref = [&](int bn, std::vector<int>& map) -> int32_t {
-      const BuildNode& c = B.nodes[bn];
-      if (c.left < 0) return leaf_ref(c.first, c.count);
-      return map[bn];
+    auto kids_of = [&](int bn) {
+      std::vector<int> kids{B.nodes[bn].left, B.nodes[bn].right};
+      while ((int)kids.size() < BVH_WIDTH) {
+        int pick = -1;
+        double best = -1.0;
+        for (int k = 0; k < (int)kids.size(); ++k)
+          if (B.nodes[kids[k]].left >= 0 && B.nodes[kids[k]].box.area() > best) best = B.nodes[kids[k]].box.area(), pick = k;
+        if (pick < 0) break;
+        const int bn2 = kids[pick];
+        kids[pick] = B.nodes[bn2].left;
+        kids.insert(kids.begin() + pick + 1, B.nodes[bn2].right);
+      }
+      return kids;
     };
-    std::vector<int> map(B.nodes.size(), -1);
-    // first pass: assign indices in DFS order
-    std::vector<int> stack{root};
-    std::vector<int> dfs;
-    while (!stack.empty()) {
-      int bn = stack.back();
-      stack.pop_back();
-      if (B.nodes[bn].left < 0) continue;
-      map[bn] = (int)dfs.size();
-      dfs.push_back(bn);
-      stack.push_back(B.nodes[bn].right);
-      stack.push_back(B.nodes[bn].left);
-    }
-    auto empty_box = [](double* lo, double* hi) {
-      for (int k = 0; k < 3; ++k) lo[k] = INFINITY, hi[k] = -INFINITY;
+    auto empty_slot = [](HostNode& hn, int k) {
+      for (int a = 0; a < 3; ++a) hn.lo[k][a] = INFINITY, hn.hi[k][a] = -INFINITY;
+      hn.c[k] = encode_leaf(0, 0, false);
     };
-    if (dfs.empty()) {
-      // the root is a leaf: wrap it in one node whose second child is empty
+    if (B.nodes[root].left < 0) {
+      // the root is a leaf: wrap it in one node with a single child
       HostNode hn;
-      for (int k = 0; k < 3; ++k) hn.lo0[k] = B.nodes[root].box.lo[k], hn.hi0[k] = B.nodes[root].box.hi[k];
-      empty_box(hn.lo1, hn.hi1);
-      hn.c0 = leaf_ref(B.nodes[root].first, B.nodes[root].count);
-      hn.c1 = encode_leaf(0, 0, false);
+      for (int k = 0; k < BVH_WIDTH; ++k) empty_slot(hn, k);
+      for (int a = 0; a < 3; ++a) hn.lo[0][a] = B.nodes[root].box.lo[a], hn.hi[0][a] = B.nodes[root].box.hi[a];
+      hn.c[0] = leaf_ref(B.nodes[root].first, B.nodes[root].count);
       out.nodes.push_back(hn);
+      out.max_depth = 1;
     } else {
-      for (int bn : dfs) {
-        const BuildNode& l = B.nodes[B.nodes[bn].left];
-        const BuildNode& r = B.nodes[B.nodes[bn].right];
+      // wide nodes in DFS order: (binary node it was grown from, its children)
+      struct Wide { int bn; std::vector<int> kids; };
+      std::vector<Wide> wide;
+      std::vector<int> map(B.nodes.size(), -1);
+      std::vector<int> stack{root};
+      while (!stack.empty()) {
+        int bn = stack.back();
+        stack.pop_back();
+        map[bn] = (int)wide.size();
+        wide.push_back({bn, kids_of(bn)});
+        const std::vector<int>& kids = wide.back().kids;
+        for (int k = (int)kids.size() - 1; k >= 0; --k)
+          if (B.nodes[kids[k]].left >= 0) stack.push_back(kids[k]);
+      }
+      std::vector<int> need(wide.size(), 0);  // stack entries a descent through this node can need
+      for (int w = (int)wide.size() - 1; w >= 0; --w) {  // children come after their parent in DFS order
+        int deepest = 0;
+        for (int kid : wide[w].kids)
+          if (B.nodes[kid].left >= 0) deepest = std::max(deepest, need[map[kid]]);
+        need[w] = (int)wide[w].kids.size() - 1 + deepest;
+      }
+      out.max_depth = need[0] + 1;
+      for (const Wide& w : wide) {
         HostNode hn;
-        for (int k = 0; k < 3; ++k) {
-          hn.lo0[k] = l.box.lo[k], hn.hi0[k] = l.box.hi[k];
-          hn.lo1[k] = r.box.lo[k], hn.hi1[k] = r.box.hi[k];
+        for (int k = 0; k < BVH_WIDTH; ++k) empty_slot(hn, k);
+        for (int k = 0; k < (int)w.kids.size(); ++k) {
+          const BuildNode& c = B.nodes[w.kids[k]];
+          for (int a = 0; a < 3; ++a) hn.lo[k][a] = c.box.lo[a], hn.hi[k][a] = c.box.hi[a];
+          hn.c[k] = c.left < 0 ? leaf_ref(c.first, c.count) : map[w.kids[k]];
         }
-        hn.c0 = child_ref(B.nodes[bn].left, map);
-        hn.c1 = child_ref(B.nodes[bn].right, map);
         out.nodes.push_back(hn);
       }
     }
   }
   for (auto& p : unbounded) out.prims.push_back(p);
   if (out.max_depth > STACK_DEPTH - 2) {
-    snprintf(err, errlen, "BVH too deep (%d)", out.max_depth);
+    snprintf(err, errlen, "BVH needs a deeper traversal stack than the kernels have (%d)", out.max_depth);
     return RT355_EINVAL;
   }
   return RT355_OK;

@@ -60,6 +60,12 @@ def render_tiles(scene, camera, max_depth, rank, world_size, out_tensor, stats=N
 
 
 def untile(device, camera, world_size, gathered, out_tensor):
+    """Tile buffers of all ranks (CUDA tensor, rank-major) -> row-major canvas, on rank 0.  The library
+    works on its own stream, so whatever produced `gathered` on torch's streams (the gather) is waited
+    for here first."""
+    import torch
+    assert gathered.is_cuda and out_tensor.is_cuda and gathered.is_contiguous() and out_tensor.is_contiguous()
+    torch.cuda.current_stream(gathered.device).synchronize()
     cd = camera.to_desc()
     _abi.check(device.lib.rt355_untile(device.handle, C.byref(cd), world_size, C.c_void_p(gathered.data_ptr()),
                                        C.c_void_p(out_tensor.data_ptr())))
