@@ -8,8 +8,8 @@
 //   k_trace      World::intersect + Intersections::hit     one thread per ray, BVH traversal
 //   k_scan       (no counterpart)                          child-ray slots of the generation: prefix sums
 //   k_spawn      n1 / n2 + reflect / refract / schlick     writes the rays of generation g+1
-//   k_shadow     is_shadowed                               off the critical path: second stream
-//   k_combine    lighting + shade_hit's final sum          run from the deepest generation back to 0
+//   k_shadow     is_shadowed + Material::lighting          off the critical path: second stream
+//   k_combine    shade_hit's final sum                     run from the deepest generation back to 0
 //
 // Every hit keeps its own record (the two child ids, the mix weight, the shadow flag), so k_combine
 // evaluates exactly the reference's expression  surface + reflected*R + refracted*(1-R)  (or
@@ -616,6 +616,12 @@ __global__ void __launch_bounds__(256) k_gen_primary(DevCamera<R> cam, RayPool<R
 // k_trace: World::intersect + hit() for every ray of generation `gen`.
 // ------------------------------------------------------------------------------------------------
 template <class R, bool COUNT, bool PACKET>
+RT_FN void shade_surface(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t r, bool valid, int p, int* lds, Work& wk);
+
+// LAST: this is the deepest generation.  Its rays spawn nothing and nothing waits for their hit records
+// except their own shading, so the kernel goes on to shade each hit (shadow ray + lighting) and leaves the
+// ray's final colour in pool.color: one launch, and one slowest-wave tail, instead of three.
+template <class R, bool COUNT, bool PACKET, bool LAST>
 __global__ void __launch_bounds__(256) k_trace(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch) {
   __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
   int* lds = PACKET ? lds_stack + (threadIdx.x >> 6) * STACK_DEPTH : lds_stack + threadIdx.x;
@@ -654,6 +660,10 @@ __global__ void __launch_bounds__(256) k_trace(DevScene<R> sc, RayPool<R> pool, 
         pool.hit_uv[2ull * r + 1] = vis.best_v;
         if (remaining > 0) n_child = ((vis.best_flags & PF_REFLECTIVE) ? 1u : 0u) + ((vis.best_flags & PF_TRANSPARENT) ? 1u : 0u);
       }
+    }
+    if constexpr (LAST) {
+      if (__ballot(hit) != 0ull) shade_surface<R, COUNT, PACKET>(sc, pool, r, hit, hit ? vis.best_p : 0, lds, wk);
+      if (valid && !hit) st3(pool.color + 3ull * r, V3<R>{R(0), R(0), R(0)});  // src/world.rs:61-63: a miss is black
     }
     // per block of rays: hits (= shadow rays) and the upper bound of child rays, for k_scan
     const uint32_t wh = __popcll(__ballot(hit)), wc = wave_sum(n_child);
@@ -841,6 +851,36 @@ RT_FN Prepared<R> prepare(const DevScene<R>& sc, const RayPool<R>& pool, uint32_
 }
 
 // ------------------------------------------------------------------------------------------------
+// shade_surface: is_shadowed (src/world.rs:45-57) of the hit of ray r, then Material::lighting
+// (src/material.rs:108-162) with that flag; the surface colour goes to pool.color[r].  Called by all 64
+// lanes (the packet traversal needs them); `valid` marks the lanes whose ray hit prim p.
+// ------------------------------------------------------------------------------------------------
+template <class R, bool COUNT, bool PACKET>
+RT_FN void shade_surface(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t r, bool valid, int p, int* lds, Work& wk) {
+  const PrimInfo info = sc.prim_info[p];
+  V3<R> over_point = {R(0), R(0), R(0)};
+  if (valid) over_point = prepare(sc, pool, r, p, info.flags).over_point;
+  const V3<R> lv = ld3(sc.light_pos) - over_point;
+  const R distance = sqrt(dot(lv, lv));
+  const V3<R> ldir = {lv.x / distance, lv.y / distance, lv.z / distance};
+  AnyVis<R, COUNT> av(sc, over_point, ldir, distance + eps<R>(), wk);
+  if constexpr (PACKET) {
+    traverse_packet<R, COUNT>(sc, over_point, ldir, valid, av, wk, lds);
+  } else {
+    if (valid) traverse<R, COUNT>(sc, over_point, ldir, av, wk, lds);
+  }
+  // The ray id goes through an opaque move so that nothing of the first prepare() stays in registers
+  // across the traversal.
+  uint32_t r2 = r;
+  asm volatile("" : "+v"(r2));
+  if (valid) {
+    const DevMaterial<R>& m = sc.materials[info.flags >> PF_MAT_SHIFT];
+    const Prepared<R> pc = prepare(sc, pool, r2, p, info.flags);
+    st3(pool.color + 3ull * r2, lighting(sc, m, pc.over_point, pc.eyev, pc.normalv, av.found));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // container_indices: n1 / n2 of prepare_computation (src/intersection.rs:86-127) for a hit on a transparent
 // shape.  The reference walks the whole sorted intersection list of the ray; what decides n1 / n2 is only
 // (a) how many of the hit shape's own intersections come before the hit and (b) the last shape entered and
@@ -924,9 +964,10 @@ RT_FN void container_indices(const DevScene<R>& sc, bool need, int p, PrimInfo i
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_shadow: is_shadowed (src/world.rs:45-57) for every hit of generation `gen`.  Nothing on the way to the
-// next generation depends on the result (only k_combine reads it), so the host runs these launches on a
-// second stream, beside the trace / spawn chain of the later generations.
+// k_shadow: is_shadowed (src/world.rs:45-57) and the surface colour (Material::lighting) of every hit of
+// generation `gen`, left in pool.color.  Nothing on the way to the next generation depends on them (only
+// k_combine reads them), so the host runs these launches on a second stream, beside the trace / spawn
+// chain of the later generations.
 // One thread per ray; lanes whose ray missed idle.
 // ------------------------------------------------------------------------------------------------
 template <class R, bool COUNT, bool PACKET>
@@ -942,20 +983,7 @@ __global__ void __launch_bounds__(256) k_shadow(DevScene<R> sc, RayPool<R> pool,
     const int p_raw = pool.hit_prim[r];
     const bool valid = i < gcount && p_raw >= 0;
     if (__ballot(valid) == 0ull) continue;  // wave-uniform
-    const int p = valid ? p_raw : 0;
-    const PrimInfo info = sc.prim_info[p];
-    V3<R> over_point = {R(0), R(0), R(0)};
-    if (valid) over_point = prepare(sc, pool, r, p, info.flags).over_point;
-    const V3<R> lv = ld3(sc.light_pos) - over_point;
-    const R distance = sqrt(dot(lv, lv));
-    const V3<R> ldir = {lv.x / distance, lv.y / distance, lv.z / distance};
-    AnyVis<R, COUNT> av(sc, over_point, ldir, distance + eps<R>(), wk);
-    if constexpr (PACKET) {
-      traverse_packet<R, COUNT>(sc, over_point, ldir, valid, av, wk, lds);
-    } else {
-      if (valid) traverse<R, COUNT>(sc, over_point, ldir, av, wk, lds);
-    }
-    if (valid) pool.shadow[r] = av.found ? 1 : 0;
+    shade_surface<R, COUNT, PACKET>(sc, pool, r, valid, valid ? p_raw : 0, lds, wk);
   }
   flush_work<COUNT>(ctl, launch, wk);
 }
@@ -1076,8 +1104,8 @@ __global__ void __launch_bounds__(256) k_spawn(DevScene<R> sc, RayPool<R> pool, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_combine: Material::lighting (src/material.rs:108-162) and shade_hit's sum (src/world.rs:117-126) for
-// every hit of generation `gen`; runs from the deepest generation back to 0, so the children's colours
+// k_combine: shade_hit's sum (src/world.rs:117-126) for every hit of generation `gen`, on top of the surface
+// colour k_shadow left in pool.color; runs from the deepest generation back to 0, so the children's colours
 // are final when their parent adds them.  Generation 0 may write the canvas directly.  `has_children` is 0
 // for the deepest generation, whose rays spawned nothing (remaining == 0: src/world.rs:69, :79).
 // ------------------------------------------------------------------------------------------------
@@ -1112,8 +1140,7 @@ __global__ void __launch_bounds__(256) k_combine(DevScene<R> sc, RayPool<R> pool
     if (p >= 0) {
       const PrimInfo info = sc.prim_info[p];
       const DevMaterial<R>& m = sc.materials[info.flags >> PF_MAT_SHIFT];
-      const Prepared<R> pc = prepare(sc, pool, r, p, info.flags);
-      const V3<R> surface = lighting(sc, m, pc.over_point, pc.eyev, pc.normalv, pool.shadow[r] != 0);
+      const V3<R> surface = ld3(pool.color + 3ull * r);  // left there by k_shadow
       int32_t cr = -1, ct = -1;
       R rs = R(-1);
       if (has_children) cr = pool.child[2ull * r], ct = pool.child[2ull * r + 1], rs = pool.mixr[r];

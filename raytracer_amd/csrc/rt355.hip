@@ -72,7 +72,7 @@ struct rt355_ctx {
   bool counting = false, timing = false;
   int exact_cones = 0;
   int packet_gens = 2;  // generations 0..packet_gens-1 use the wave-packet traversal
-  DevBuf org, dir, hit_t, hit_uv, hit_prim, color, mixr, shadow, child, blk_hits, blk_children, blk_base, ctl, io_in, io_out, io_out2;
+  DevBuf org, dir, hit_t, hit_uv, hit_prim, color, mixr, child, blk_hits, blk_children, blk_base, ctl, io_in, io_out, io_out2;
   hipEvent_t ev[RT355_MAX_LAUNCH + 1];
   bool ev_ok = false, side_ok = false;
   FrameCtl* ctl_host = nullptr;  // pinned
@@ -163,7 +163,6 @@ int ensure_pool(rt355_ctx* c, uint64_t n_primary, bool secondary, RayPool<R>& po
   if ((rc = c->hit_prim.ensure(cap * sizeof(int32_t)))) return rc;
   if ((rc = c->color.ensure(cap * 3 * sizeof(R)))) return rc;
   if ((rc = c->mixr.ensure(cap * sizeof(R)))) return rc;
-  if ((rc = c->shadow.ensure(cap))) return rc;
   if ((rc = c->child.ensure(cap * 2 * sizeof(int32_t)))) return rc;
   const uint64_t nblk = cap / BLOCK + 2;
   if ((rc = c->blk_hits.ensure(nblk * sizeof(uint32_t)))) return rc;
@@ -172,7 +171,6 @@ int ensure_pool(rt355_ctx* c, uint64_t n_primary, bool secondary, RayPool<R>& po
   if ((rc = c->ctl.ensure(sizeof(FrameCtl)))) return rc;
   pool.org = (R*)c->org.p, pool.dir = (R*)c->dir.p, pool.hit_t = (R*)c->hit_t.p, pool.hit_uv = (R*)c->hit_uv.p;
   pool.hit_prim = (int32_t*)c->hit_prim.p, pool.color = (R*)c->color.p, pool.mixr = (R*)c->mixr.p;
-  pool.shadow = (uint8_t*)c->shadow.p;
   pool.child = (int32_t*)c->child.p;
   pool.blk_hits = (uint32_t*)c->blk_hits.p, pool.blk_children = (uint32_t*)c->blk_children.p, pool.blk_base = (uint32_t*)c->blk_base.p;
   pool.capacity = (int64_t)cap;
@@ -181,6 +179,7 @@ int ensure_pool(rt355_ctx* c, uint64_t n_primary, bool secondary, RayPool<R>& po
 
 struct LaunchLog {
   int n = 0;
+  int depth = 0;  // deepest generation: its trace launch also shades
   int kind[RT355_MAX_LAUNCH], gen[RT355_MAX_LAUNCH];
 };
 
@@ -202,7 +201,7 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, uint32
     return RT355_OK;
   };
   // Shadow rays feed nothing but k_combine, so they leave the critical path: with per-launch timing or
-  // counting off they run on the side stream, each generation as soon as its trace has finished.
+  // counting off they run on the side stream.
   const bool overlap = !c->timing && !COUNT;
   for (int g = 0; g <= depth; ++g) {
     // generation g > 0 can hold at most twice the hits of g-1; its size is only known on the device
@@ -210,47 +209,49 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, uint32
     int rc;
     if ((rc = rec(RT355_K_TRACE, g))) return rc;
     const bool packet = g < c->packet_gens;
-    if (packet)
-      hipLaunchKernelGGL((k_trace<R, COUNT, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n);
+    const bool last = g == depth;
+    if (packet && last)
+      hipLaunchKernelGGL((k_trace<R, COUNT, true, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, 0, log.n);
+    else if (packet)
+      hipLaunchKernelGGL((k_trace<R, COUNT, true, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n);
+    else if (last)
+      hipLaunchKernelGGL((k_trace<R, COUNT, false, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, 0, log.n);
     else
-      hipLaunchKernelGGL((k_trace<R, COUNT, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n);
+      hipLaunchKernelGGL((k_trace<R, COUNT, false, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n);
     log.n++;
-    hipStream_t shadow_stream = c->stream;
-    if (overlap) {
-      HIP_TRY(hipEventRecord(c->ev_traced[g], c->stream));
-      HIP_TRY(hipStreamWaitEvent(c->side, c->ev_traced[g], 0));
-      shadow_stream = c->side;
-    }
-    auto shadow = [&]() {
-      int rc2;
-      if ((rc2 = rec(RT355_K_SHADE, g))) return rc2;
-      if (packet)
-        hipLaunchKernelGGL((k_shadow<R, COUNT, true>), dim3(grid), dim3(block), 0, shadow_stream, sc, pool, ctl, g, log.n);
-      else
-        hipLaunchKernelGGL((k_shadow<R, COUNT, false>), dim3(grid), dim3(block), 0, shadow_stream, sc, pool, ctl, g, log.n);
-      log.n++;
-      return (int)RT355_OK;
-    };
-    if (overlap && (rc = shadow())) return rc;
-    if (g < depth) {
-      hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, pool.blk_hits, pool.blk_children, pool.blk_base, ctl, g, (long long)pool.capacity);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, pool.blk_hits, pool.blk_children, pool.blk_base, ctl, g, (long long)pool.capacity);
+    if (g < depth) {  // the deepest generation spawns nothing
       if ((rc = rec(RT355_K_SPAWN, g))) return rc;
       if (packet)
         hipLaunchKernelGGL((k_spawn<R, COUNT, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, s->any_transparent ? 1 : 0, log.n);
       else
         hipLaunchKernelGGL((k_spawn<R, COUNT, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, s->any_transparent ? 1 : 0, log.n);
       log.n++;
-    } else {
-      // the deepest generation spawns nothing; the scan still totals its hits
-      hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, pool.blk_hits, pool.blk_children, pool.blk_base, ctl, g, (long long)pool.capacity);
     }
-    if (!overlap && (rc = shadow())) return rc;
+    if (last) break;  // shaded inside the trace launch
+    // The shadow launch of this generation is released only now, behind the spawn: the next trace then
+    // reaches the device first and the shadow waves fill the SIMDs its tail leaves idle, instead of
+    // taking the block slots the spawn is waiting for.
+    hipStream_t shadow_stream = c->stream;
+    if (overlap) {
+      HIP_TRY(hipEventRecord(c->ev_traced[g], c->stream));
+      HIP_TRY(hipStreamWaitEvent(c->side, c->ev_traced[g], 0));
+      shadow_stream = c->side;
+    }
+    if ((rc = rec(RT355_K_SHADE, g))) return rc;
+    if (packet)
+      hipLaunchKernelGGL((k_shadow<R, COUNT, true>), dim3(grid), dim3(block), 0, shadow_stream, sc, pool, ctl, g, log.n);
+    else
+      hipLaunchKernelGGL((k_shadow<R, COUNT, false>), dim3(grid), dim3(block), 0, shadow_stream, sc, pool, ctl, g, log.n);
+    log.n++;
   }
-  if (overlap) {
+  log.depth = depth;
+  if (overlap && depth > 0) {
     HIP_TRY(hipEventRecord(c->ev_side_done, c->side));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_side_done, 0));
   }
-  for (int g = depth; g >= 0; --g) {
+  // the deepest generation's colours are final already; generation 0 still has to reach the canvas
+  for (int g = depth > 0 ? depth - 1 : 0; g >= 0; --g) {
     const uint32_t grid = g == 0 ? grid0 : std::min<uint32_t>(grid_cap, (uint32_t)((pool.capacity + BLOCK - 1) / BLOCK));
     int rc;
     if ((rc = rec(RT355_K_COMBINE, g))) return rc;
@@ -299,9 +300,10 @@ int finish_stats(rt355_ctx* c, const LaunchLog& log, double frame_ms, rt355_stat
       st->launch_max_box_tests[i] = w[10];
       st->launch_max_wave_clocks[i] = w[11];
       const int g = log.gen[i];
-      if (log.kind[i] == RT355_K_SHADE) fl += F_PREPARE * (double)hits_of[g];  // over_point of every hit
+      if (log.kind[i] == RT355_K_SHADE || (log.kind[i] == RT355_K_TRACE && g == log.depth))
+        fl += (F_PREPARE + F_SHADE) * (double)hits_of[g];  // over_point + lighting of every hit
       if (log.kind[i] == RT355_K_SPAWN) fl += 0.5 * (F_REFLECT + F_REFRACT) * (double)h.gen_count[g + 1].v;
-      if (log.kind[i] == RT355_K_COMBINE) fl += F_SHADE * (double)hits_of[g];
+      if (log.kind[i] == RT355_K_COMBINE) fl += 8.0 * (double)hits_of[g];  // surface + refl * R + refr * (1 - R)
       st->launch_flops[i] = fl;
     }
   }
@@ -358,7 +360,7 @@ int rays_impl(rt355_ctx* c, const rt355_scene* s, const float* rays_host, size_t
   if (trace_only) {
     DevScene<R> sc = dev_scene<R>(s);
     hipLaunchKernelGGL(k_reset_ctl, dim3(1), dim3(256), 0, c->stream, (FrameCtl*)c->ctl.p, (uint32_t)n);
-    hipLaunchKernelGGL((k_trace<R, false, false>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (FrameCtl*)c->ctl.p, 0, 0, 0);
+    hipLaunchKernelGGL((k_trace<R, false, false, false>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (FrameCtl*)c->ctl.p, 0, 0, 0);
     if ((rc = c->io_out.ensure(n * sizeof(double)))) return rc;
     if ((rc = c->io_out2.ensure(n * sizeof(int32_t)))) return rc;
     hipLaunchKernelGGL((k_export_hits<R>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (uint32_t)n, (double*)c->io_out.p, (int32_t*)c->io_out2.p);
@@ -482,7 +484,13 @@ int rt355_ctx_create(rt355_ctx** out, int device_id, int real_bits) {
   c->device = device_id, c->real_bits = real_bits;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+  // The main stream carries the chain every generation waits on and gets the highest priority the device
+  // offers; the side stream (shadow launches) the lowest, so that its waves fill idle SIMDs instead of
+  // competing for them.
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  if (getenv("RT355_NO_PRIORITY")) prio_least = prio_greatest = 0;
+  if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) {
     delete c;
     return set_err(RT355_EHIP, "hipStreamCreate failed");
   }
@@ -492,7 +500,7 @@ int rt355_ctx_create(rt355_ctx** out, int device_id, int real_bits) {
       return set_err(RT355_EHIP, "hipEventCreate failed");
     }
   c->ev_ok = true;
-  bool side_ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
+  bool side_ok = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_least) == hipSuccess;
   for (int i = 0; i < RT355_MAX_GEN && side_ok; ++i) side_ok = hipEventCreateWithFlags(&c->ev_traced[i], hipEventDisableTiming) == hipSuccess;
   side_ok = side_ok && hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming) == hipSuccess;
   if (!side_ok) {
@@ -515,7 +523,7 @@ void rt355_ctx_destroy(rt355_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->side) (void)hipStreamSynchronize(c->side);
-  for (DevBuf* b : {&c->org, &c->dir, &c->hit_t, &c->hit_uv, &c->hit_prim, &c->color, &c->mixr, &c->shadow, &c->child, &c->blk_hits, &c->blk_children, &c->blk_base, &c->ctl, &c->io_in, &c->io_out, &c->io_out2}) b->release();
+  for (DevBuf* b : {&c->org, &c->dir, &c->hit_t, &c->hit_uv, &c->hit_prim, &c->color, &c->mixr, &c->child, &c->blk_hits, &c->blk_children, &c->blk_base, &c->ctl, &c->io_in, &c->io_out, &c->io_out2}) b->release();
   if (c->ev_ok)
     for (int i = 0; i <= RT355_MAX_LAUNCH; ++i) (void)hipEventDestroy(c->ev[i]);
   if (c->side_ok) {

@@ -110,10 +110,9 @@ struct RayPool {
   R* hit_t;    // nearest t >= 0
   R* hit_uv;   // 2 per ray (smooth triangles)
   int32_t* hit_prim;   // prim id, -1 = miss
-  R* color;    // 3 per ray: colour of the ray (color_at), written by the combine pass
+  R* color;    // 3 per ray: surface colour of the hit (k_shadow), then the colour of the ray (k_combine)
   R* mixr;     // schlick reflectance of the hit (< 0: plain sum)
   int32_t* child;      // 2 per ray: reflected, refracted child ray id (-1 = none)
-  uint8_t* shadow;     // is_shadowed(over_point) of the hit
   // Child-ray slots are handed out without atomics: k_trace leaves, per block of BLOCK rays, the number of
   // hits and an upper bound of the children they can spawn; k_scan turns the bounds into exclusive
   // prefixes; k_spawn places its children at prefix + rank inside the block.
