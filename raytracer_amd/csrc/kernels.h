@@ -594,11 +594,9 @@ RT_FN bool pixel_of(const DevCamera<R>& cam, uint32_t i, int& x, int& y, int& ti
 }
 
 template <class R>
-__global__ void __launch_bounds__(256) k_gen_primary(DevCamera<R> cam, RayPool<R> pool, uint32_t n) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+RT_FN void primary_ray(const DevCamera<R>& cam, uint32_t i, V3<R>& org, V3<R>& dir) {
   int x, y, tl, it;
-  V3<R> org = {R(0), R(0), R(0)}, dir = {R(0), R(0), R(0)};  // zero direction = inactive ray
+  org = {R(0), R(0), R(0)}, dir = {R(0), R(0), R(0)};  // zero direction = inactive ray (tile padding)
   if (pixel_of(cam, i, x, y, tl, it)) {
     const R x_offset = (R(x) + R(0.5)) * cam.pixel_size;
     const R y_offset = (R(y) + R(0.5)) * cam.pixel_size;
@@ -608,12 +606,11 @@ __global__ void __launch_bounds__(256) k_gen_primary(DevCamera<R> cam, RayPool<R
     org = xf_point(cam.inv, mk<R>(R(0), R(0), R(0)));
     dir = normalize(pixel - org);
   }
-  st3(pool.org + 3ull * i, org);
-  st3(pool.dir + 3ull * i, dir);
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_trace: World::intersect + hit() for every ray of generation `gen`.
+// k_trace: World::intersect + hit() for every ray of generation `gen`.  With `primary` set (generation 0
+// of a frame) the rays come from the camera instead of the pool.
 // ------------------------------------------------------------------------------------------------
 template <class R, bool COUNT, bool PACKET>
 RT_FN void shade_surface(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t r, bool valid, int p, int* lds, Work& wk);
@@ -622,7 +619,7 @@ RT_FN void shade_surface(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t
 // except their own shading, so the kernel goes on to shade each hit (shadow ray + lighting) and leaves the
 // ray's final colour in pool.color: one launch, and one slowest-wave tail, instead of three.
 template <class R, bool COUNT, bool PACKET, bool LAST>
-__global__ void __launch_bounds__(256) k_trace(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch) {
+__global__ void __launch_bounds__(256) k_trace(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch, DevCamera<R> cam, int primary) {
   __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
   int* lds = PACKET ? lds_stack + (threadIdx.x >> 6) * STACK_DEPTH : lds_stack + threadIdx.x;
   uint32_t start, count;
@@ -635,7 +632,13 @@ __global__ void __launch_bounds__(256) k_trace(DevScene<R> sc, RayPool<R> pool, 
     const uint32_t i = base + threadIdx.x;
     const bool valid = i < count;
     const uint32_t r = start + (valid ? i : 0u);
-    const V3<R> o = ld3(pool.org + 3ull * r), d = ld3(pool.dir + 3ull * r);
+    V3<R> o, d;
+    if (primary) {  // generation 0 of a frame: the rays are made here and kept for the later kernels
+      primary_ray(cam, r, o, d);
+      if (valid) st3(pool.org + 3ull * r, o), st3(pool.dir + 3ull * r, d);
+    } else {
+      o = ld3(pool.org + 3ull * r), d = ld3(pool.dir + 3ull * r);
+    }
     ClosestVis<R, COUNT> vis(sc, o, d, wk);
     const bool live = valid && !(d.x == R(0) && d.y == R(0) && d.z == R(0));
     long long t_start = 0;
@@ -695,7 +698,7 @@ __global__ void __launch_bounds__(256) k_reset_ctl(FrameCtl* ctl, uint32_t n_pri
 // function of the ray order, so a frame always lays its rays out the same way.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) k_scan(const uint32_t* blk_hits, const uint32_t* blk_children, uint32_t* blk_base, FrameCtl* ctl, int gen, long long capacity) {
-  __shared__ uint32_t s_c[1024], s_h[1024];
+  __shared__ uint32_t s_c[16], s_h[16];
   uint32_t start, count;
   gen_range(ctl, gen, capacity, start, count);
   const uint32_t n = (count + BLOCK - 1) / BLOCK;
@@ -703,23 +706,26 @@ __global__ void __launch_bounds__(1024) k_scan(const uint32_t* blk_hits, const u
   const uint32_t lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
   uint32_t c = 0, h = 0;
   for (uint32_t k = lo; k < hi; ++k) c += blk_children[k], h += blk_hits[k];
-  s_c[threadIdx.x] = c, s_h[threadIdx.x] = h;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-    uint32_t vc = 0, vh = 0;
-    if ((int)threadIdx.x >= off) vc = s_c[threadIdx.x - off], vh = s_h[threadIdx.x - off];
-    __syncthreads();
-    s_c[threadIdx.x] += vc, s_h[threadIdx.x] += vh;
-    __syncthreads();
+  // inclusive scan inside each wave by shuffles, then the 16 wave totals through LDS: one barrier
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t ic = c, ih = h;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t tc = __shfl_up(ic, off), th = __shfl_up(ih, off);
+    if ((int)lane >= off) ic += tc, ih += th;
   }
-  uint32_t run = s_c[threadIdx.x] - c;
+  if (lane == 63u) s_c[wave] = ic, s_h[wave] = ih;
+  __syncthreads();
+  uint32_t pc = 0, ph = 0;
+  for (uint32_t w = 0; w < wave; ++w) pc += s_c[w], ph += s_h[w];
+  uint32_t run = pc + ic - c;
   for (uint32_t k = lo; k < hi; ++k) {
     blk_base[k] = run;
     run += blk_children[k];
   }
   if (threadIdx.x == 1023) {
-    ctl->hit_count[gen].v = s_h[1023];
-    unsigned long long total = s_c[1023];
+    ctl->hit_count[gen].v = ph + ih;
+    unsigned long long total = pc + ic;
     const unsigned long long room = (unsigned long long)capacity - ((unsigned long long)start + count);
     if (total > room) total = room, ctl->overflow.v = 1;
     ctl->gen_count[gen + 1].v = (uint32_t)total;

@@ -183,10 +183,11 @@ struct LaunchLog {
   int kind[RT355_MAX_LAUNCH], gen[RT355_MAX_LAUNCH];
 };
 
-// The frame: generation 0 rays are already in the pool (ids 0..n_primary).  Leaves the combined
+// The frame.  Generation 0 (ids 0..n_primary) is either made from the camera by the first trace launch
+// (`primary`) or already in the pool.  Leaves the combined
 // generation-0 colours in pool.color[0..n_primary).
 template <class R, bool COUNT>
-int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, uint32_t n_primary, int max_depth, const DevCamera<R>& cam,
+int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, uint32_t n_primary, int max_depth, const DevCamera<R>& cam, bool primary,
                     int out_mode, float* out_dev, LaunchLog& log) {
   DevScene<R> sc = dev_scene<R>(s);
   FrameCtl* ctl = (FrameCtl*)c->ctl.p;
@@ -211,13 +212,13 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, uint32
     const bool packet = g < c->packet_gens;
     const bool last = g == depth;
     if (packet && last)
-      hipLaunchKernelGGL((k_trace<R, COUNT, true, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, 0, log.n);
+      hipLaunchKernelGGL((k_trace<R, COUNT, true, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, 0, log.n, cam, (g == 0 && primary) ? 1 : 0);
     else if (packet)
-      hipLaunchKernelGGL((k_trace<R, COUNT, true, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n);
+      hipLaunchKernelGGL((k_trace<R, COUNT, true, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n, cam, (g == 0 && primary) ? 1 : 0);
     else if (last)
-      hipLaunchKernelGGL((k_trace<R, COUNT, false, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, 0, log.n);
+      hipLaunchKernelGGL((k_trace<R, COUNT, false, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, 0, log.n, cam, (g == 0 && primary) ? 1 : 0);
     else
-      hipLaunchKernelGGL((k_trace<R, COUNT, false, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n);
+      hipLaunchKernelGGL((k_trace<R, COUNT, false, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n, cam, (g == 0 && primary) ? 1 : 0);
     log.n++;
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, pool.blk_hits, pool.blk_children, pool.blk_base, ctl, g, (long long)pool.capacity);
     if (g < depth) {  // the deepest generation spawns nothing
@@ -321,14 +322,11 @@ int render_impl(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam
   RayPool<R> pool;
   if ((rc = ensure_pool<R>(c, n_primary, s->any_secondary && max_depth > 0, pool))) return rc;
   auto t0 = std::chrono::steady_clock::now();
-  const int block = 256;
-  const uint32_t grid0 = (uint32_t)((n_primary + block - 1) / block);
-  hipLaunchKernelGGL((k_gen_primary<R>), dim3(grid0), dim3(block), 0, c->stream, dc, pool, (uint32_t)n_primary);
   LaunchLog log;
   if (c->counting)
-    rc = run_generations<R, true>(c, s, pool, (uint32_t)n_primary, max_depth, dc, out_mode, out_dev, log);
+    rc = run_generations<R, true>(c, s, pool, (uint32_t)n_primary, max_depth, dc, true, out_mode, out_dev, log);
   else
-    rc = run_generations<R, false>(c, s, pool, (uint32_t)n_primary, max_depth, dc, out_mode, out_dev, log);
+    rc = run_generations<R, false>(c, s, pool, (uint32_t)n_primary, max_depth, dc, true, out_mode, out_dev, log);
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
   bool overflow = false;
@@ -360,7 +358,7 @@ int rays_impl(rt355_ctx* c, const rt355_scene* s, const float* rays_host, size_t
   if (trace_only) {
     DevScene<R> sc = dev_scene<R>(s);
     hipLaunchKernelGGL(k_reset_ctl, dim3(1), dim3(256), 0, c->stream, (FrameCtl*)c->ctl.p, (uint32_t)n);
-    hipLaunchKernelGGL((k_trace<R, false, false, false>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (FrameCtl*)c->ctl.p, 0, 0, 0);
+    hipLaunchKernelGGL((k_trace<R, false, false, false>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (FrameCtl*)c->ctl.p, 0, 0, 0, DevCamera<R>{}, 0);
     if ((rc = c->io_out.ensure(n * sizeof(double)))) return rc;
     if ((rc = c->io_out2.ensure(n * sizeof(int32_t)))) return rc;
     hipLaunchKernelGGL((k_export_hits<R>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (uint32_t)n, (double*)c->io_out.p, (int32_t*)c->io_out2.p);
@@ -375,9 +373,9 @@ int rays_impl(rt355_ctx* c, const rt355_scene* s, const float* rays_host, size_t
   DevCamera<R> dummy;
   memset(&dummy, 0, sizeof(dummy));
   if (c->counting)
-    rc = run_generations<R, true>(c, s, pool, (uint32_t)n, max_depth, dummy, (int)OUT_LINEAR, (float*)c->io_out.p, log);
+    rc = run_generations<R, true>(c, s, pool, (uint32_t)n, max_depth, dummy, false, (int)OUT_LINEAR, (float*)c->io_out.p, log);
   else
-    rc = run_generations<R, false>(c, s, pool, (uint32_t)n, max_depth, dummy, (int)OUT_LINEAR, (float*)c->io_out.p, log);
+    rc = run_generations<R, false>(c, s, pool, (uint32_t)n, max_depth, dummy, false, (int)OUT_LINEAR, (float*)c->io_out.p, log);
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(rgb_out, c->io_out.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));

@@ -9,8 +9,8 @@ python3 - "$f" <<'PY'
 import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# last frame: from the last k_gen_primary on
-idx = max(i for i, r in enumerate(rows) if "k_gen_primary" in r["Kernel_Name"])
+# last frame: from the last k_reset_ctl on
+idx = max(i for i, r in enumerate(rows) if "k_reset_ctl" in r["Kernel_Name"])
 fr = rows[idx:]
 t0 = int(fr[0]["Start_Timestamp"])
 for r in fr:
