@@ -74,14 +74,29 @@ template <class R> RT_FN V3<R> xf_vec(const R* r, V3<R> v) {
 struct Work {  // per-thread work counters (counting mode only)
   uint32_t box = 0, xf = 0, prim[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
+// Counters of one thread -> FrameCtl.  Reduced over the wave first (every lane of the wave calls this at
+// the end of its kernel), so the per-launch totals cost 11 atomics per wave, not per lane.
 template <bool COUNT> RT_FN void flush_work(FrameCtl* ctl, int launch, const Work& w) {
   if constexpr (COUNT) {
     if (launch >= RT355_MAX_LAUNCH) return;
-    if (w.box) atomicAdd(&ctl->work[launch][0], (unsigned long long)w.box);
-    if (w.box) atomicMax(&ctl->work[launch][10], (unsigned long long)w.box);  // longest traversal of one lane
-    if (w.xf) atomicAdd(&ctl->work[launch][1], (unsigned long long)w.xf);
+    auto wsum = [](uint32_t v) {
+      unsigned long long t = v;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+      return t;
+    };
+    uint32_t mx = w.box;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, off));
+    const unsigned long long box = wsum(w.box), xf = wsum(w.xf);
+    unsigned long long prim[8];
+    for (int k = 0; k < 8; ++k) prim[k] = wsum(w.prim[k]);
+    if ((threadIdx.x & 63u) != 0) return;
+    if (box) atomicAdd(&ctl->work[launch][0], box);
+    if (mx) atomicMax(&ctl->work[launch][10], (unsigned long long)mx);  // longest traversal of one lane
+    if (xf) atomicAdd(&ctl->work[launch][1], xf);
     for (int k = 0; k < 8; ++k)
-      if (w.prim[k]) atomicAdd(&ctl->work[launch][2 + k], (unsigned long long)w.prim[k]);
+      if (prim[k]) atomicAdd(&ctl->work[launch][2 + k], prim[k]);
   }
 }
 
