@@ -7,7 +7,8 @@ shadows, reflection / refraction depth 5, 1920x1080 -- on N MI355X of one node.
            --master-port P bench.py --gpus N --steps K --warmup W
 
 A step is ONE frame: every rank renders its 32x32 tiles (tile t -> rank t % N, scene replicated), the
-rank tile buffers are gathered to rank 0 (torch.distributed.gather = RCCL over xGMI) and un-tiled there.
+rank tile buffers are gathered to rank 0 (torch.distributed.gather = RCCL over xGMI) and un-tiled there;
+with one rank the canvas is written row-major in place (same kernels, no gather).
 The scene is uploaded once, before the timed region; all inputs are resident in HBM when timing starts.
 Rank 0 prints one JSON line.  `value` counts the rays actually traced: one radiance ray per color_at
 call plus one shadow ray per hit (src/world.rs:58-66, :105), summed over all ranks.
@@ -82,14 +83,13 @@ def main():
     st = Stats()
 
     def step():
+        if world_size == 1:  # one rank owns every tile: the canvas is written in place, nothing to gather
+            rd.render_canvas(scene, cam, args.depth, canvas, st)
+            return
         rd.render_tiles(scene, cam, args.depth, rank, world_size, local, st)
-        if world_size > 1:
-            dist.gather(local, bufs, dst=0)
-            src = gathered
-        else:
-            src = local
+        dist.gather(local, bufs, dst=0)
         if rank == 0:
-            rd.untile(dev, cam, world_size, src, canvas)
+            rd.untile(dev, cam, world_size, gathered, canvas)
 
     def fence():
         torch.cuda.synchronize()

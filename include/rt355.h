@@ -164,6 +164,12 @@ int rt355_scene_info(const rt355_scene*, uint64_t out[5]);
 int rt355_render(rt355_ctx*, const rt355_scene*, const rt355_camera_desc* cam, int max_depth,
                  float* rgb_out, rt355_stats* stats /* nullable */);
 
+/* Camera::render again, with the canvas left in DEVICE memory (`rgb_out_dev`: hsize*vsize*3 floats,
+ * same layout as rt355_render): for callers that go on working on the GPU (tone mapping, encoding, a
+ * single-GPU frame loop).  Synchronous with respect to the host. */
+int rt355_render_device(rt355_ctx*, const rt355_scene*, const rt355_camera_desc* cam, int max_depth,
+                        float* rgb_out_dev, rt355_stats* stats /* nullable */);
+
 /* Same frame, rank `rank` of `n_ranks` renders only its 32x32 tiles (tile t belongs to rank
  * t % n_ranks) into DEVICE memory `tiles_out`: rt355_tiles_per_rank() * 1024 * 3 floats, tile-major,
  * pixels of a tile row-major.  With n_ranks == 1 this is the whole frame in tile order.

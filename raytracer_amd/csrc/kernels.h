@@ -1115,7 +1115,7 @@ __global__ void __launch_bounds__(256) k_spawn(DevScene<R> sc, RayPool<R> pool, 
         ctl->overflow.v = 1;
       }
     }
-    if (valid) {
+    if (slot_r || slot_t) {  // k_combine looks at these only for hits on reflective / transparent shapes
       pool.child[2ull * r] = child_r;
       pool.child[2ull * r + 1] = child_t;
       pool.mixr[r] = rs;
@@ -1164,7 +1164,7 @@ __global__ void __launch_bounds__(256) k_combine(DevScene<R> sc, RayPool<R> pool
       const V3<R> surface = ld3(pool.color + 3ull * r);  // left there by k_shadow
       int32_t cr = -1, ct = -1;
       R rs = R(-1);
-      if (has_children) cr = pool.child[2ull * r], ct = pool.child[2ull * r + 1], rs = pool.mixr[r];
+      if (has_children && (info.flags & (PF_REFLECTIVE | PF_TRANSPARENT))) cr = pool.child[2ull * r], ct = pool.child[2ull * r + 1], rs = pool.mixr[r];
       V3<R> refl = {R(0), R(0), R(0)}, refr = {R(0), R(0), R(0)};
       if (cr >= 0) refl = ld3(pool.color + 3ull * cr) * m.reflective;
       if (ct >= 0) refr = ld3(pool.color + 3ull * ct) * m.transparency;

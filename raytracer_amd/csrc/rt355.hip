@@ -622,6 +622,14 @@ int rt355_render(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* ca
   return RT355_OK;
 }
 
+int rt355_render_device(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam, int max_depth, float* rgb_out_dev, rt355_stats* stats) {
+  int rc = check_render_args(c, s, cam, max_depth);
+  if (rc) return rc;
+  if (!rgb_out_dev) return set_err(RT355_EINVAL, "null output");
+  return c->real_bits == 32 ? render_impl<float>(c, s, cam, max_depth, 0, 1, OUT_ROWMAJOR, rgb_out_dev, stats)
+                            : render_impl<double>(c, s, cam, max_depth, 0, 1, OUT_ROWMAJOR, rgb_out_dev, stats);
+}
+
 int rt355_render_tiles(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam, int max_depth, int rank, int n_ranks,
                        float* tiles_out_dev, rt355_stats* stats) {
   int rc = check_render_args(c, s, cam, max_depth);

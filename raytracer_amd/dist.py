@@ -59,6 +59,16 @@ def render_tiles(scene, camera, max_depth, rank, world_size, out_tensor, stats=N
                                             C.c_void_p(out_tensor.data_ptr()), C.byref(stats) if stats is not None else None))
 
 
+def render_canvas(scene, camera, max_depth, out_tensor, stats=None):
+    """The whole frame, row-major, into `out_tensor` (a CUDA float32 tensor of height*width*3 elements):
+    what a single rank does, where there is nothing to gather or un-tile."""
+    cd = camera.to_desc()
+    need = int(camera.horizontal_size) * int(camera.vertical_size) * 3
+    assert out_tensor.is_cuda and out_tensor.is_contiguous() and out_tensor.numel() == need
+    _abi.check(scene.lib.rt355_render_device(scene.device.handle, scene.handle, C.byref(cd), max_depth,
+                                             C.c_void_p(out_tensor.data_ptr()), C.byref(stats) if stats is not None else None))
+
+
 def untile(device, camera, world_size, gathered, out_tensor):
     """Tile buffers of all ranks (CUDA tensor, rank-major) -> row-major canvas, on rank 0.  The library
     works on its own stream, so whatever produced `gathered` on torch's streams (the gather) is waited

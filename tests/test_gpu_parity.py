@@ -376,3 +376,16 @@ def test_deepest_recursion_with_instrumentation(dev, oracle):
     dev_radiance = int(st.total_radiance) - int(st.radiance_rays[0]) + 64 * 48  # generation 0 includes tile padding
     assert abs(dev_radiance - tot_o) <= max(8, 0.03 * tot_o)
     assert abs(int(st.total_shadow) - int(cnt["hits"].sum())) <= max(8, 0.03 * tot_o)
+
+
+def test_render_device_equals_render(dev):
+    """rt355_render_device leaves in HBM exactly the canvas rt355_render copies to the host."""
+    import torch
+    from raytracer_amd import dist as rd
+    world, cam = scenes.glass(70, 45)
+    scene = dev.upload(world)
+    want = scene.render(cam, 5).pixels
+    out = torch.empty(45 * 70 * 3, dtype=torch.float32, device="cuda")
+    rd.render_canvas(scene, cam, 5, out)
+    scene.close()
+    assert np.array_equal(out.cpu().numpy().reshape(45, 70, 3), want)
