@@ -5,6 +5,7 @@
 // device-side control block that the kernels read (grid-stride loops over device-side counts), and the
 // block is read back once, after the frame, for the statistics.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <chrono>
 #include <cmath>
@@ -72,6 +73,7 @@ struct rt355_ctx {
   bool counting = false, timing = false;
   int exact_cones = 0;
   int packet_gens = 2;  // generations 0..packet_gens-1 use the wave-packet traversal
+  int shadow_lag = 0;   // the shadow launch of generation g is released behind the spawn of generation g + lag
   DevBuf org, dir, hit_t, hit_uv, hit_prim, color, mixr, child, blk_hits, blk_children, blk_base, ctl, io_in, io_out, io_out2;
   hipEvent_t ev[RT355_MAX_LAUNCH + 1];
   bool ev_ok = false, side_ok = false;
@@ -223,28 +225,43 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, uint32
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, pool.blk_hits, pool.blk_children, pool.blk_base, ctl, g, (long long)pool.capacity);
     if (g < depth) {  // the deepest generation spawns nothing
       if ((rc = rec(RT355_K_SPAWN, g))) return rc;
+      // with the side stream in use, the event it waits for rides on this launch's own completion signal:
+      // a separate event record would put a marker packet, and some microseconds, between spawn and trace
+      hipEvent_t done = overlap ? c->ev_traced[g] : nullptr;
+      const int any_t = s->any_transparent ? 1 : 0, launch_id = log.n;
       if (packet)
-        hipLaunchKernelGGL((k_spawn<R, COUNT, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, s->any_transparent ? 1 : 0, log.n);
+        hipExtLaunchKernelGGL((k_spawn<R, COUNT, true>), dim3(grid), dim3(block), 0, c->stream, nullptr, done, 0, sc, pool, ctl, g, any_t, launch_id);
       else
-        hipLaunchKernelGGL((k_spawn<R, COUNT, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, s->any_transparent ? 1 : 0, log.n);
+        hipExtLaunchKernelGGL((k_spawn<R, COUNT, false>), dim3(grid), dim3(block), 0, c->stream, nullptr, done, 0, sc, pool, ctl, g, any_t, launch_id);
       log.n++;
     }
-    if (last) break;  // shaded inside the trace launch
-    // The shadow launch of this generation is released only now, behind the spawn: the next trace then
-    // reaches the device first and the shadow waves fill the SIMDs its tail leaves idle, instead of
-    // taking the block slots the spawn is waiting for.
-    hipStream_t shadow_stream = c->stream;
-    if (overlap) {
-      HIP_TRY(hipEventRecord(c->ev_traced[g], c->stream));
-      HIP_TRY(hipStreamWaitEvent(c->side, c->ev_traced[g], 0));
-      shadow_stream = c->side;
+    // Shadow launches.  The one of generation g - lag is released here, behind the spawn of generation g:
+    // the next trace then reaches the device first and the shadow waves fill the SIMDs its tail leaves
+    // idle, instead of taking the block slots the chain is waiting for.
+    auto shadow = [&](int sg, hipStream_t st) {
+      const uint32_t sgrid = sg == 0 ? grid0 : std::min<uint32_t>(grid_cap, (uint32_t)((pool.capacity + BLOCK - 1) / BLOCK));
+      int rc2;
+      if ((rc2 = rec(RT355_K_SHADE, sg))) return rc2;
+      if (sg < c->packet_gens)
+        hipLaunchKernelGGL((k_shadow<R, COUNT, true>), dim3(sgrid), dim3(block), 0, st, sc, pool, ctl, sg, log.n);
+      else
+        hipLaunchKernelGGL((k_shadow<R, COUNT, false>), dim3(sgrid), dim3(block), 0, st, sc, pool, ctl, sg, log.n);
+      log.n++;
+      return (int)RT355_OK;
+    };
+    if (!overlap) {
+      if (!last && (rc = shadow(g, c->stream))) return rc;  // the deepest generation shades inside its trace
+      continue;
     }
-    if ((rc = rec(RT355_K_SHADE, g))) return rc;
-    if (packet)
-      hipLaunchKernelGGL((k_shadow<R, COUNT, true>), dim3(grid), dim3(block), 0, shadow_stream, sc, pool, ctl, g, log.n);
-    else
-      hipLaunchKernelGGL((k_shadow<R, COUNT, false>), dim3(grid), dim3(block), 0, shadow_stream, sc, pool, ctl, g, log.n);
-    log.n++;
+    const int lag = c->shadow_lag;
+    if (!last) {
+      HIP_TRY(hipStreamWaitEvent(c->side, c->ev_traced[g], 0));
+      if (g - lag >= 0 && (rc = shadow(g - lag, c->side))) return rc;
+    } else {
+      // every generation still waiting: their traces finished long ago
+      for (int sg = std::max(0, g - lag); sg < g; ++sg)
+        if ((rc = shadow(sg, c->side))) return rc;
+    }
   }
   log.depth = depth;
   if (overlap && depth > 0) {
@@ -512,6 +529,7 @@ int rt355_ctx_create(rt355_ctx** out, int device_id, int real_bits) {
     return set_err(RT355_ENOMEM, "pinned host allocation failed");
   }
   if (const char* e = getenv("RT355_PACKET_GENS")) c->packet_gens = atoi(e);
+  if (const char* e = getenv("RT355_SHADOW_LAG")) c->shadow_lag = std::max(0, atoi(e));
   *out = c;
   return RT355_OK;
 }
