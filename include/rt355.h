@@ -201,6 +201,15 @@ int rt355_is_shadowed(rt355_ctx*, const rt355_scene*, const float* points, size_
 /* Color::to_u8 (src/color.rs:97-111) on the device: n floats -> n bytes, both HOST memory. */
 int rt355_to_u8(rt355_ctx*, const float* rgb, size_t n, uint8_t* out);
 
+/* Host only, needs no GPU: builds the scene tables and the BVH exactly as rt355_scene_upload does
+ * (real_bits picks the box padding) and checks their structure: every bounded shape in exactly one
+ * leaf, every child box enclosing what lies beneath it, the traversal stack bound.  out[0]=nodes,
+ * out[1]=bounded prims, out[2]=unbounded prims, out[3]=stack entries a descent can need,
+ * out[4]=distinct materials.  Returns RT355_EINVAL with a message when the input is rejected or the
+ * check fails. */
+int rt355_scene_check(const rt355_shape_desc* shapes, size_t n_shapes, int real_bits, int exact_cones,
+                      uint64_t out[5]);
+
 /* Algorithmic FLOP weights used for launch_flops: out[0]=primary ray, [1]=box test,
  * [2]=ray->object transform, [3..10]=local_intersect per rt355_kind, [11]=shading per hit,
  * [12]=reflect spawn, [13]=refract spawn, [14]=schlick. */

@@ -727,6 +727,20 @@ int rt355_to_u8(rt355_ctx* c, const float* rgb, size_t n, uint8_t* out) {
   return RT355_OK;
 }
 
+int rt355_scene_check(const rt355_shape_desc* shapes, size_t n_shapes, int real_bits, int exact_cones, uint64_t out[5]) {
+  if ((!shapes && n_shapes) || !out) return set_err(RT355_EINVAL, "null argument");
+  if (real_bits != 32 && real_bits != 64) return set_err(RT355_EINVAL, "real_bits must be 32 or 64");
+  HostScene hs;
+  char err[256] = {0};
+  const double pad_rel = real_bits == 32 ? 256.0 * 1.1920929e-7 : 1e-9;
+  int rc = build_host_scene(shapes, n_shapes, pad_rel, exact_cones ? INT64_MAX : 32, hs, err, sizeof(err));
+  if (rc) return set_err(rc, err);
+  if ((rc = verify_host_scene(hs, err, sizeof(err)))) return set_err(rc, err);
+  out[0] = hs.nodes.size(), out[1] = (uint64_t)hs.n_bounded, out[2] = hs.prims.size() - (size_t)hs.n_bounded;
+  out[3] = (uint64_t)hs.max_depth, out[4] = hs.materials.size();
+  return RT355_OK;
+}
+
 void rt355_flop_table(double out[16]) {
   out[0] = F_PRIMARY, out[1] = F_BOX, out[2] = F_XFORM;
   for (int k = 0; k < 8; ++k) out[3 + k] = F_KIND[k];

@@ -170,4 +170,7 @@ struct HostScene {
 // cone_exact_limit: scenes with at most this many truncated cones keep them in the every-ray list.
 int build_host_scene(const rt355_shape_desc* shapes, size_t n, double pad_rel, int64_t cone_exact_limit, HostScene& out, char* err, size_t errlen);
 
+// Host-side structural check of a built scene (scene_build.cpp); 0 or RT355_EINVAL with a message.
+int verify_host_scene(const HostScene& hs, char* err, size_t errlen);
+
 }  // namespace rt355

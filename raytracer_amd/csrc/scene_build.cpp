@@ -421,4 +421,82 @@ int build_host_scene(const rt355_shape_desc* shapes, size_t n, double pad_rel, i
   return RT355_OK;
 }
 
+// Structural check of a built scene, on the host: every bounded prim sits in exactly one leaf, every child
+// box encloses the boxes of all prims beneath it, inner nodes are reachable exactly once, and no descent can
+// need more stack entries than max_depth says.  Returns 0 or RT355_EINVAL with a message.
+int verify_host_scene(const HostScene& hs, char* err, size_t errlen) {
+  const int nb = hs.n_bounded;
+  if (hs.nodes.empty()) {
+    if (nb != 0) { snprintf(err, errlen, "bounded prims but no nodes"); return RT355_EINVAL; }
+    return RT355_OK;
+  }
+  std::vector<int> seen_prim(nb, 0), seen_node(hs.nodes.size(), 0);
+  struct Item { int node; int stack; };
+  std::vector<Item> todo{{0, 0}};
+  int worst = 0;
+  seen_node[0] = 1;
+  // boxes of the subtree under (node, child) are checked against that child's box by a second walk
+  std::vector<std::pair<int, int>> sub;
+  while (!todo.empty()) {
+    Item it = todo.back();
+    todo.pop_back();
+    const HostNode& n = hs.nodes[it.node];
+    int kids = 0;
+    for (int k = 0; k < BVH_WIDTH; ++k) kids += n.c[k] != -1;
+    if (kids == 0) { snprintf(err, errlen, "node %d has no children", it.node); return RT355_EINVAL; }
+    const int stack_here = it.stack + kids - 1;
+    worst = std::max(worst, stack_here);
+    for (int k = 0; k < BVH_WIDTH; ++k) {
+      if (n.c[k] == -1) {
+        if (!(n.lo[k][0] > n.hi[k][0])) { snprintf(err, errlen, "empty slot of node %d has a box", it.node); return RT355_EINVAL; }
+        continue;
+      }
+      // collect the prims beneath this child
+      sub.clear();
+      std::vector<int> walk{n.c[k]};
+      while (!walk.empty()) {
+        int c = walk.back();
+        walk.pop_back();
+        if (c >= 0) {
+          if (c >= (int)hs.nodes.size()) { snprintf(err, errlen, "child index out of range"); return RT355_EINVAL; }
+          for (int j = 0; j < BVH_WIDTH; ++j)
+            if (hs.nodes[c].c[j] != -1) walk.push_back(hs.nodes[c].c[j]);
+        } else {
+          const uint32_t leaf = (uint32_t)~c;
+          sub.push_back({(int)(leaf & LEAF_FIRST_MASK), (int)(leaf >> 26)});
+        }
+      }
+      for (auto& fc : sub)
+        for (int q = fc.first; q < fc.first + fc.second; ++q) {
+          if (q < 0 || q >= nb) { snprintf(err, errlen, "leaf range out of bounds"); return RT355_EINVAL; }
+          const HostPrim& pr = hs.prims[q];
+          for (int a = 0; a < 3; ++a)
+            if (pr.lo[a] < n.lo[k][a] || pr.hi[a] > n.hi[k][a]) {
+              snprintf(err, errlen, "prim %d sticks out of child %d of node %d", q, k, it.node);
+              return RT355_EINVAL;
+            }
+        }
+      if (n.c[k] >= 0) {
+        if (seen_node[n.c[k]]++) { snprintf(err, errlen, "node %d reached twice", n.c[k]); return RT355_EINVAL; }
+        todo.push_back({n.c[k], it.stack + kids - 1});
+      } else {
+        const uint32_t leaf = (uint32_t)~n.c[k];
+        const int first = (int)(leaf & LEAF_FIRST_MASK), count = (int)(leaf >> 26);
+        const bool tri_only = (leaf & LEAF_TRI_BIT) != 0;
+        for (int q = first; q < first + count; ++q) {
+          seen_prim[q]++;
+          const bool is_tri = (hs.prims[q].flags & PF_KIND_MASK) >= RT355_TRIANGLE && (hs.prims[q].flags & PF_IDENTITY);
+          if (tri_only && !is_tri) { snprintf(err, errlen, "triangle-only leaf holds prim %d of another kind", q); return RT355_EINVAL; }
+        }
+      }
+    }
+  }
+  for (int q = 0; q < nb; ++q)
+    if (seen_prim[q] != 1) { snprintf(err, errlen, "prim %d is in %d leaves", q, seen_prim[q]); return RT355_EINVAL; }
+  for (size_t i = 0; i < hs.nodes.size(); ++i)
+    if (!seen_node[i]) { snprintf(err, errlen, "node %zu is unreachable", i); return RT355_EINVAL; }
+  if (worst + 1 > hs.max_depth) { snprintf(err, errlen, "a descent needs %d stack entries, recorded %d", worst + 1, hs.max_depth); return RT355_EINVAL; }
+  return RT355_OK;
+}
+
 }  // namespace rt355

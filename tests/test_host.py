@@ -415,3 +415,47 @@ def test_tile_render_of_the_oracle_assembles_to_the_full_frame(oracle):
         b[idx >= 0] = full.reshape(-1, 3)[idx[idx >= 0]]
         bufs.append(b.reshape(-1))
     assert (rd.untile_host(np.stack(bufs), 48, 40, n) == full).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# Scene tables + BVH built on the host (no GPU): rt355_scene_check
+# ------------------------------------------------------------------------------------------------
+def _check(world, real_bits=64, exact_cones=0):
+    out = (C.c_uint64 * 5)()
+    rc = _abi.lib().rt355_scene_check(world.descs(), world.n_shapes(), real_bits, exact_cones, out)
+    return rc, dict(nodes=out[0], bounded=out[1], unbounded=out[2], stack=out[3], materials=out[4])
+
+
+@pytest.mark.parametrize("real_bits", [32, 64])
+def test_bvh_structure_teapot(real_bits):
+    world, _ = scenes.north_star(64, 36)
+    rc, info = _check(world, real_bits)
+    assert rc == 0, _abi.lib().rt355_last_error()
+    assert info["bounded"] == 6321 and info["unbounded"] == 1  # teapot + sphere in the BVH, the floor plane beside it
+    assert 6321 / 4 / 3 <= info["nodes"] <= 6321  # 4-wide nodes over leaves of up to 4 triangles
+    assert info["stack"] <= 62
+    assert info["materials"] == 3  # de-duplicated: teapot, floor, glass
+
+
+def test_bvh_structure_mixed_and_degenerate_inputs():
+    world, _ = scenes.stress(64, 36, n_top=2, n_mid=10, n_leaf=50, extent=60.0)
+    rc, info = _check(world)
+    assert rc == 0, _abi.lib().rt355_last_error()
+    assert info["bounded"] == 1000 and info["unbounded"] == 1  # groups are inert placeholders, the floor is unbounded
+    rc, info = _check(world, exact_cones=1)  # truncated cones move to the every-ray list
+    assert rc == 0 and info["unbounded"] == 1 + 250 and info["bounded"] == 750
+    # one shape, no shape, groups only, many coincident shapes
+    for shapes, bounded in ([Shape.Sphere()], 1), ([], 0), ([Shape.Group(), Shape.Group()], 0), ([Shape.Cube() for _ in range(40)], 40):
+        rc, info = _check(World(None, shapes))
+        assert rc == 0 and info["bounded"] == bounded, (_abi.lib().rt355_last_error(), info)
+
+
+def test_scene_check_rejects_what_the_reference_panics_on():
+    lib = _abi.lib()
+    out = (C.c_uint64 * 5)()
+    singular = World(None, [Shape.Sphere(mx.scaling(1, 0, 1))])  # try_inverse().unwrap() in src/ray.rs:34
+    assert lib.rt355_scene_check(singular.descs(), 1, 64, 0, out) == -1
+    assert b"singular" in lib.rt355_last_error() or b"invert" in lib.rt355_last_error()
+    nan = World(None, [Shape.Sphere(mx.translation(float("nan"), 0, 0))])
+    assert lib.rt355_scene_check(nan.descs(), 1, 64, 0, out) == -1
+    assert lib.rt355_scene_check(singular.descs(), 1, 48, 0, out) == -1
