@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--real", type=int, default=64, choices=[32, 64])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="all ranks on GPU 0 with the gloo backend: walks the N>1 code path on a one-GPU box (numbers are meaningless)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -67,9 +69,14 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", 1))
     if world_size != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run")
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world_size > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     world, cam = scenes.CONFIGS[args.scene](args.width, args.height)
     w, h = args.width, args.height
