@@ -166,14 +166,16 @@ def main():
         gens = list(st.launch_gen[: st.n_launch])
         k = int(np.argmax(ms_l))
         achieved = flops[k] / (ms_l[k] * 1e-3) / 1e12
+        kernel_name = f"{KIND_NAME.get(kinds[k], '?')} generation {gens[k]}"
+        traffic = _measured_traffic(kernel_name) if (args.scene, w, h, args.depth, args.real, world_size) == ("north_star", 1920, 1080, 5, 64, 1) else None
         out["roofline"] = {
             "bound": "valu_fp64" if args.real == 64 else "valu_fp32",
-            "kernel": f"{KIND_NAME.get(kinds[k], '?')} generation {gens[k]}",
+            "kernel": kernel_name,
             "achieved": round(achieved, 4),
             "peak": FP64_VALU_PEAK_TFLOPS if args.real == 64 else 2 * FP64_VALU_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(achieved / (FP64_VALU_PEAK_TFLOPS if args.real == 64 else 2 * FP64_VALU_PEAK_TFLOPS), 5),
-            "traffic": None,
+            "traffic": traffic,
             "flops_per_launch": float(flops[k]),
             "launch_ms": round(float(ms_l[k]), 4),
             "frame_flops": float(flops.sum()),
@@ -189,6 +191,16 @@ def main():
     if world_size > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _measured_traffic(kernel_name):
+    """HBM bytes of one launch of the named kernel on the headline workload, from the committed PMC passes
+    (a bench run cannot collect hardware counters itself); None when there is no such measurement."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+            return int(json.load(fh)["launches"][kernel_name]["bytes"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def _active_pixels(w, h, rank, world_size):
