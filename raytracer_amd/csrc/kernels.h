@@ -539,18 +539,21 @@ struct BackwardVis {
   int p_hit;
   R bound_t;   // forward t of the bound, exclusive together with bound_s
   int bound_s;
+  R floor_t;   // forward t below which nothing is of interest, exclusive together with floor_s
+  int floor_s;
   bool have;
   R ct;        // forward t of the candidate
   int cs, cp, cflags;
-  RT_FN BackwardVis(const DevScene<R>& s, V3<R> o_, V3<R> d_, int ph, R bt, int bs, Work& w)
-      : sc(s), o(o_), d(d_), wk(w), p_hit(ph), bound_t(bt), bound_s(bs), have(false), ct(-inf<R>()), cs(-1), cp(-1), cflags(0) {}
+  RT_FN BackwardVis(const DevScene<R>& s, V3<R> o_, V3<R> d_, int ph, R bt, int bs, R ft, int fs, Work& w)
+      : sc(s), o(o_), d(d_), wk(w), p_hit(ph), bound_t(bt), bound_s(bs), floor_t(ft), floor_s(fs), have(false), ct(-inf<R>()), cs(-1), cp(-1), cflags(0) {}
   RT_FN R tmin() const { return -bound_t; }
-  RT_FN R tmax() const { return -ct; }
+  RT_FN R tmax() const { return have ? -ct : -floor_t; }
   RT_FN void accept(R tr, int p, int shape, int flags) {
     const R t = -tr;
     const bool below = t < bound_t || (t == bound_t && shape < bound_s);
+    const bool above = t > floor_t || (t == floor_t && shape > floor_s);
     const bool better = !have || t > ct || (t == ct && shape > cs);
-    if (below && better) have = true, ct = t, cs = shape, cp = p, cflags = flags;  // NaN fails `below`
+    if (below && above && better) have = true, ct = t, cs = shape, cp = p, cflags = flags;  // NaN fails `below`
   }
   RT_FN bool prim(int p) {
     if (p == p_hit) return false;
@@ -943,16 +946,24 @@ RT_FN void container_indices(const DevScene<R>& sc, bool need, int p, PrimInfo i
       if (c_before == 0 || ht[k] >= hmt) hmt = ht[k];
       ++c_before;
     }
-  // the container's last element among the OTHER shapes: walk backwards from the hit
+  // the container's last element among the OTHER shapes: walk backwards from the hit.
+  // When every other shape has refractive index 1 the walk only has to tell whether some shape was
+  // entered AFTER the hit shape's own last event (then n1 is that shape's 1 and not the hit shape's
+  // index): nothing to look for when the ray is entering the hit shape, and nothing behind that event
+  // otherwise.
+  const bool h_before = (c_before & 1) != 0;
+  const bool others_unit = (info.flags & PF_OTHERS_UNIT) != 0;
+  const R floor_t = (others_unit && h_before) ? hmt : -inf<R>();
+  const int floor_s = (others_unit && h_before) ? info.shape : -1;
   const V3<R> rd = R(-1) * d;
-  bool searching = need, found = false;
+  bool searching = need && !(others_unit && !h_before), found = false;
   int other_flags = 0, other_s = -1;
   R other_t = R(0);
   R bound_t = t;
   int bound_s = info.shape;
   for (int step = 0; step < 4096; ++step) {
     if (PACKET ? (__ballot(searching) == 0ull) : !searching) break;
-    BackwardVis<R, COUNT> bv(sc, o, rd, p, bound_t, bound_s, wk);
+    BackwardVis<R, COUNT> bv(sc, o, rd, p, bound_t, bound_s, floor_t, floor_s, wk);
     if constexpr (PACKET) {
       traverse_packet<R, COUNT>(sc, o, rd, searching, bv, wk, lds);
     } else {
@@ -978,7 +989,6 @@ RT_FN void container_indices(const DevScene<R>& sc, bool need, int p, PrimInfo i
   }
   const R own = sc.materials[info.flags >> PF_MAT_SHIFT].refractive;
   const R other = found ? sc.materials[other_flags >> PF_MAT_SHIFT].refractive : R(1);
-  const bool h_before = (c_before & 1) != 0;
   const bool own_last = h_before && (!found || hmt > other_t || (hmt == other_t && info.shape > other_s));
   n1 = own_last ? own : other;
   n2 = ((c_before + 1) & 1) ? own : other;

@@ -436,6 +436,10 @@ int upload_impl(rt355_ctx* c, const HostScene& hs, rt355_scene* s) {
     xf[i].ymin = (R)p.ymin, xf[i].ymax = (R)p.ymax, xf[i].pad0 = xf[i].pad1 = 0;
     if ((p.flags & PF_KIND_MASK) >= RT355_TRIANGLE) any_tri = true;
   }
+  size_t n_optical = 0;  // prims whose refractive index is not 1 (the default, src/material.rs:31-72)
+  for (size_t i = 0; i < np; ++i) n_optical += hs.materials[hs.prims[i].material].refractive != 1.f;
+  for (size_t i = 0; i < np; ++i)
+    if (n_optical == (hs.materials[hs.prims[i].material].refractive != 1.f ? 1u : 0u)) info[i].flags |= PF_OTHERS_UNIT;
   std::vector<DevTri> tri(any_tri ? np : 0);
   std::vector<DevTriNormals<R>> trin(any_tri ? np : 0);
   if (any_tri)

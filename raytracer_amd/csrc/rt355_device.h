@@ -33,6 +33,7 @@ constexpr int PF_CLOSED = 8;
 constexpr int PF_IDENTITY = 16;  // transformation is exactly the identity: the ray is used as is
 constexpr int PF_REFLECTIVE = 32;   // material.reflective != 0: a hit may spawn a reflected ray
 constexpr int PF_TRANSPARENT = 64;  // material.transparency != 0: a hit may spawn a refracted ray
+constexpr int PF_OTHERS_UNIT = 128;  // every OTHER prim of the scene has refractive index 1: n1 / n2 need less searching
 constexpr int PF_MAT_SHIFT = 8;
 
 struct PrimInfo {

@@ -432,3 +432,42 @@ def test_headline_frame_at_full_size(oracle):
     bad = (np.abs(oracle.to_u8(got).astype(int) - oracle.to_u8(want).astype(int)).max(axis=1) > 1).mean()
     print(f"headline frame: {bad:.3%} of 400 sampled pixels differ by more than 1/255")
     assert bad <= 0.01
+
+
+@pytest.mark.parametrize("second_index", [1.0, 1.3])
+def test_refractive_indices_with_overlapping_shapes(dev, oracle, second_index):
+    """n1 / n2 (src/intersection.rs:86-127) where shapes overlap: a glass sphere intersecting a transparent
+    sphere, both over a floor, rays starting inside and outside.  With second_index 1.0 every shape but the
+    glass one has refractive index 1, which lets the device skip most of the container search; with 1.3 it
+    cannot.  Both must give the oracle's colours."""
+    glass = Material.new_glass()
+    glass.reflective = 0.3
+    other = Material(color=(0.2, 0.8, 0.3), transparency=0.6, refractive=second_index, reflective=0.1 if second_index != 1.0 else 0.0)
+    floor = Material(color=(0.9, 0.9, 0.9), reflective=0.2)
+    floor.pattern = Pattern.Checker((1, 1, 1), (0.1, 0.1, 0.1))
+    world = World(PointLight((-4, 6, -5), (1, 1, 1)), [
+        Shape.Sphere(mx.translation(0, 0, 0), glass),
+        Shape.Sphere(mx.translation(0.9, 0.2, 0.3) @ mx.scaling(1.2, 1.2, 1.2), other),
+        Shape.Cube(mx.translation(-1.2, 0, 0.5) @ mx.scaling(0.6, 0.6, 0.6), Material(color=(0.8, 0.3, 0.2))),
+        Shape.Plane(mx.translation(0, -1.5, 0), floor),
+    ])
+    rng = np.random.default_rng(17)
+    n = 6000
+    org = rng.uniform(-2.5, 2.5, (n, 3))
+    org[: n // 2] *= 0.3  # half of the rays start inside one or both spheres
+    tgt = rng.uniform(-1.0, 1.0, (n, 3))
+    d = tgt - org
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, d], axis=1).astype(np.float32)
+    scene = dev.upload(world)
+    dev.set_pool(64.0)  # every hit may spawn two rays here: 1 + 2 + ... + 32 per primary ray at most
+    try:
+        got = scene.color_at(rays, 5)
+    finally:
+        dev.set_pool(8.0)
+        scene.close()
+    want = oracle.color_at(world, rays, 5, dev.real_bits)
+    tol = 1e-4 if dev.real_bits == 64 else 2e-2
+    bad = (np.abs(got - want).max(axis=1) > tol).mean()
+    print(f"overlapping shapes, index {second_index}, real={dev.real_bits}: {bad:.3%} of {n} rays differ by more than {tol}")
+    assert bad <= (0.003 if dev.real_bits == 64 else 0.03)
