@@ -68,15 +68,14 @@ struct rt355_ctx {
   int real_bits = 64;
   hipStream_t stream = nullptr;
   hipStream_t side = nullptr;  // shadow launches, beside the trace / spawn chain
-  hipEvent_t ev_traced[RT355_MAX_GEN], ev_side_done;
+  hipEvent_t ev_traced[RT355_MAX_GEN] = {}, ev_side_done = nullptr;
   double pool_factor = 8.0;
   bool counting = false, timing = false;
   int exact_cones = 0;
   int packet_gens = 2;  // generations 0..packet_gens-1 use the wave-packet traversal
   int shadow_lag = 0;   // the shadow launch of generation g is released behind the spawn of generation g + lag
   DevBuf org, dir, hit_t, hit_uv, hit_prim, color, mixr, child, blk_hits, blk_children, blk_base, ctl, io_in, io_out, io_out2;
-  hipEvent_t ev[RT355_MAX_LAUNCH + 1];
-  bool ev_ok = false, side_ok = false;
+  hipEvent_t ev[RT355_MAX_LAUNCH + 1] = {};  // timing mode: one before every launch, one behind the last
   FrameCtl* ctl_host = nullptr;  // pinned
   int n_cu = 256;
 };
@@ -503,30 +502,20 @@ int rt355_ctx_create(rt355_ctx** out, int device_id, int real_bits) {
   c->device = device_id, c->real_bits = real_bits;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
-  // The main stream carries the chain every generation waits on and gets the highest priority the device
-  // offers; the side stream (shadow launches) the lowest, so that its waves fill idle SIMDs instead of
-  // competing for them.
+  // Main stream: the chain every generation waits on, at the highest priority the device offers.  Side
+  // stream: the shadow launches, at the lowest, so that their waves yield to the chain's (measured: 2 % of
+  // the frame).
   int prio_least = 0, prio_greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-  if (getenv("RT355_NO_PRIORITY")) prio_least = prio_greatest = 0;
-  if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) {
-    delete c;
-    return set_err(RT355_EHIP, "hipStreamCreate failed");
+  bool ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
+            hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_least) == hipSuccess;
+  for (int i = 0; i <= RT355_MAX_LAUNCH && ok; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+  for (int i = 0; i < RT355_MAX_GEN && ok; ++i) ok = hipEventCreateWithFlags(&c->ev_traced[i], hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    rt355_ctx_destroy(c);  // releases whatever was created
+    return set_err(RT355_EHIP, "stream / event creation failed");
   }
-  for (int i = 0; i <= RT355_MAX_LAUNCH; ++i)
-    if (hipEventCreate(&c->ev[i]) != hipSuccess) {
-      delete c;
-      return set_err(RT355_EHIP, "hipEventCreate failed");
-    }
-  c->ev_ok = true;
-  bool side_ok = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_least) == hipSuccess;
-  for (int i = 0; i < RT355_MAX_GEN && side_ok; ++i) side_ok = hipEventCreateWithFlags(&c->ev_traced[i], hipEventDisableTiming) == hipSuccess;
-  side_ok = side_ok && hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming) == hipSuccess;
-  if (!side_ok) {
-    delete c;  // the process keeps whatever was created; this only happens when the runtime is unusable
-    return set_err(RT355_EHIP, "side stream / event creation failed");
-  }
-  c->side_ok = true;
   if (hipHostMalloc((void**)&c->ctl_host, sizeof(FrameCtl), hipHostMallocDefault) != hipSuccess) {
     c->ctl_host = nullptr;
     rt355_ctx_destroy(c);
@@ -544,12 +533,11 @@ void rt355_ctx_destroy(rt355_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->side) (void)hipStreamSynchronize(c->side);
   for (DevBuf* b : {&c->org, &c->dir, &c->hit_t, &c->hit_uv, &c->hit_prim, &c->color, &c->mixr, &c->child, &c->blk_hits, &c->blk_children, &c->blk_base, &c->ctl, &c->io_in, &c->io_out, &c->io_out2}) b->release();
-  if (c->ev_ok)
-    for (int i = 0; i <= RT355_MAX_LAUNCH; ++i) (void)hipEventDestroy(c->ev[i]);
-  if (c->side_ok) {
-    for (int i = 0; i < RT355_MAX_GEN; ++i) (void)hipEventDestroy(c->ev_traced[i]);
-    (void)hipEventDestroy(c->ev_side_done);
-  }
+  for (hipEvent_t e : c->ev)
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->ev_traced)
+    if (e) (void)hipEventDestroy(e);
+  if (c->ev_side_done) (void)hipEventDestroy(c->ev_side_done);
   if (c->side) (void)hipStreamDestroy(c->side);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->ctl_host) (void)hipHostFree(c->ctl_host);
