@@ -637,7 +637,7 @@ RT_FN void shade_surface(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t
 // except their own shading, so the kernel goes on to shade each hit (shadow ray + lighting) and leaves the
 // ray's final colour in pool.color: one launch, and one slowest-wave tail, instead of three.
 template <class R, bool COUNT, bool PACKET, bool LAST>
-__global__ void __launch_bounds__(256) k_trace(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch, DevCamera<R> cam, int primary) {
+__global__ void __launch_bounds__(256, (PACKET && !LAST) ? 4 : 3) k_trace(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch, DevCamera<R> cam, int primary) {
   __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
   int* lds = PACKET ? lds_stack + (threadIdx.x >> 6) * STACK_DEPTH : lds_stack + threadIdx.x;
   uint32_t start, count;
@@ -1002,7 +1002,7 @@ RT_FN void container_indices(const DevScene<R>& sc, bool need, int p, PrimInfo i
 // One thread per ray; lanes whose ray missed idle.
 // ------------------------------------------------------------------------------------------------
 template <class R, bool COUNT, bool PACKET>
-__global__ void __launch_bounds__(256) k_shadow(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int launch) {
+__global__ void __launch_bounds__(256, PACKET ? 4 : 3) k_shadow(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int launch) {
   uint32_t start, gcount;
   gen_range(ctl, gen, pool.capacity, start, gcount);
   __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
@@ -1026,7 +1026,7 @@ __global__ void __launch_bounds__(256) k_shadow(DevScene<R> sc, RayPool<R> pool,
 // children and k_combine is told so.
 // ------------------------------------------------------------------------------------------------
 template <class R, bool COUNT, bool PACKET>
-__global__ void __launch_bounds__(256) k_spawn(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int any_transparent, int launch) {
+__global__ void __launch_bounds__(256, 3) k_spawn(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int any_transparent, int launch) {
   __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
   int* lds = PACKET ? lds_stack + (threadIdx.x >> 6) * STACK_DEPTH : lds_stack + threadIdx.x;
   Work wk;
