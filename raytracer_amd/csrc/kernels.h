@@ -882,25 +882,21 @@ RT_FN Prepared<R> prepare(const DevScene<R>& sc, const RayPool<R>& pool, uint32_
 template <class R, bool COUNT, bool PACKET>
 RT_FN void shade_surface(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t r, bool valid, int p, int* lds, Work& wk) {
   const PrimInfo info = sc.prim_info[p];
-  V3<R> over_point = {R(0), R(0), R(0)};
-  if (valid) over_point = prepare(sc, pool, r, p, info.flags).over_point;
-  const V3<R> lv = ld3(sc.light_pos) - over_point;
+  Prepared<R> pc;
+  pc.over_point = {R(0), R(0), R(0)};
+  if (valid) pc = prepare(sc, pool, r, p, info.flags);
+  const V3<R> lv = ld3(sc.light_pos) - pc.over_point;
   const R distance = sqrt(dot(lv, lv));
   const V3<R> ldir = {lv.x / distance, lv.y / distance, lv.z / distance};
-  AnyVis<R, COUNT> av(sc, over_point, ldir, distance + eps<R>(), wk);
+  AnyVis<R, COUNT> av(sc, pc.over_point, ldir, distance + eps<R>(), wk);
   if constexpr (PACKET) {
-    traverse_packet<R, COUNT>(sc, over_point, ldir, valid, av, wk, lds);
+    traverse_packet<R, COUNT>(sc, pc.over_point, ldir, valid, av, wk, lds);
   } else {
-    if (valid) traverse<R, COUNT>(sc, over_point, ldir, av, wk, lds);
+    if (valid) traverse<R, COUNT>(sc, pc.over_point, ldir, av, wk, lds);
   }
-  // The ray id goes through an opaque move so that nothing of the first prepare() stays in registers
-  // across the traversal.
-  uint32_t r2 = r;
-  asm volatile("" : "+v"(r2));
   if (valid) {
     const DevMaterial<R>& m = sc.materials[info.flags >> PF_MAT_SHIFT];
-    const Prepared<R> pc = prepare(sc, pool, r2, p, info.flags);
-    st3(pool.color + 3ull * r2, lighting(sc, m, pc.over_point, pc.eyev, pc.normalv, av.found));
+    st3(pool.color + 3ull * r, lighting(sc, m, pc.over_point, pc.eyev, pc.normalv, av.found));
   }
 }
 
