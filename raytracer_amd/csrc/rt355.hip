@@ -72,7 +72,7 @@ struct rt355_ctx {
   double pool_factor = 8.0;
   bool counting = false, timing = false;
   int exact_cones = 0;
-  int packet_gens = 2;  // generations 0..packet_gens-1 use the wave-packet traversal
+  int packet_gens = 1;  // generations 0..packet_gens-1 use the wave-packet traversal (primary rays and their shadow rays)
   int shadow_lag = 0;   // the shadow launch of generation g is released behind the spawn of generation g + lag
   DevBuf org, dir, hit_t, hit_uv, hit_prim, color, mixr, child, blk_hits, blk_children, blk_base, ctl, io_in, io_out, io_out2;
   hipEvent_t ev[RT355_MAX_LAUNCH + 1] = {};  // timing mode: one before every launch, one behind the last
