@@ -471,3 +471,23 @@ def test_refractive_indices_with_overlapping_shapes(dev, oracle, second_index):
     bad = (np.abs(got - want).max(axis=1) > tol).mean()
     print(f"overlapping shapes, index {second_index}, real={dev.real_bits}: {bad:.3%} of {n} rays differ by more than {tol}")
     assert bad <= (0.003 if dev.real_bits == 64 else 0.03)
+
+
+def test_cpp_host_mirror_renders_like_the_python_one(tmp_path):
+    """include/rt355.hpp: the reference's camera test (src/camera.rs:155-169) and its default scene
+    (src/main.rs:202-273) written against the C++ mirror; the canvas must equal the one the Python mirror
+    gets for the same scene (same library underneath; the two hosts build their matrices independently)."""
+    import os
+    import subprocess
+    from raytracer_amd.host import Color
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "cpp", "host_mirror_test")
+    assert os.path.exists(exe), "run `python -c 'import __graft_entry__ as g; g.build()'` first"
+    out = tmp_path / "ch9.f32"
+    r = subprocess.run([exe, "--gpu", str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.fromfile(out, dtype=np.float32).reshape(150, 200, 3)
+    world, cam = scenes.ch9(200, 150)
+    want = cam.render(world, 5, Device.get(0, 64)).pixels
+    d = np.abs(Color.to_u8(got).astype(int) - Color.to_u8(want).astype(int))
+    assert (d.max(axis=2) > 1).mean() <= 0.001
+    assert np.abs(got - want).max() < 0.05

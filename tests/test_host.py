@@ -459,3 +459,18 @@ def test_scene_check_rejects_what_the_reference_panics_on():
     nan = World(None, [Shape.Sphere(mx.translation(float("nan"), 0, 0))])
     assert lib.rt355_scene_check(nan.descs(), 1, 64, 0, out) == -1
     assert lib.rt355_scene_check(singular.descs(), 1, 48, 0, out) == -1
+
+
+# ------------------------------------------------------------------------------------------------
+# C++ host mirror (include/rt355.hpp): its own test program, built by __graft_entry__.build()
+# ------------------------------------------------------------------------------------------------
+CPP_TEST = os.path.join(ROOT, "tests", "cpp", "host_mirror_test")
+
+
+def test_cpp_host_mirror_cpu_part():
+    """Matrix / view-transformation / camera / colour / PPM known answers of the reference and the ABI
+    records the C++ types fill, with no GPU."""
+    assert os.path.exists(CPP_TEST), "run `python -c 'import __graft_entry__ as g; g.build()'` first"
+    r = subprocess.run([CPP_TEST, "--cpu"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "cpu: 0 failure(s)" in r.stdout
