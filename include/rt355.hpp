@@ -20,8 +20,10 @@
 
 #include <cmath>
 #include <cstdint>
+#include <fstream>
 #include <limits>
 #include <optional>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -282,6 +284,113 @@ struct Shape {
     float* dst[6] = {d.p1, d.p2, d.p3, d.n1, d.n2, d.n3};
     for (int k = 0; k < 6; ++k) dst[k][0] = src[k]->x, dst[k][1] = src[k]->y, dst[k][2] = src[k]->z;
     return d;
+  }
+};
+
+// ---- group.rs: the scene tree and its flattening ---------------------------------------------------
+// `Scene::to_transformed_shapes` (src/group.rs:117-168) runs on the host before the render path: a World
+// only ever holds a flat list in which Group entries are inert.  The reference composes only the IMMEDIATE
+// parent group's transformation into a child (src/group.rs:146: the recursion re-reads the child's original
+// transformation, so outer groups do not accumulate), pushes the root and every child in depth-first
+// order, and lets children of a non-group node pass through unchanged.  accumulate = true composes the
+// whole parent chain instead (the evident intent), for new scenes.
+struct Node {
+  Shape shape;
+  std::vector<Node> children;
+  explicit Node(Shape s) : shape(std::move(s)) {}
+  Node& add(Shape s) {
+    children.emplace_back(std::move(s));
+    return children.back();
+  }
+};
+inline void fold_transformation(const Node& node, const Matrix4* carried, bool accumulate, std::vector<Shape>& out) {
+  const bool is_group = node.shape.kind == RT355_GROUP;
+  for (const Node& ch : node.children) {
+    Shape s = ch.shape;
+    if (is_group) s.transformation = (accumulate && carried ? *carried : node.shape.transformation) * ch.shape.transformation;
+    out.push_back(s);
+    const Matrix4 next = is_group ? s.transformation : ch.shape.transformation;
+    fold_transformation(ch, accumulate ? &next : nullptr, accumulate, out);
+  }
+}
+inline std::vector<Shape> to_transformed_shapes(const Node& root, bool accumulate = false) {
+  std::vector<Shape> out{root.shape};
+  fold_transformation(root, accumulate ? &root.shape.transformation : nullptr, accumulate, out);
+  return out;
+}
+
+// ---- wavefront.rs: OBJ -> smooth triangles ------------------------------------------------------------
+// `Wavefront::parse` (src/wavefront.rs:39-184): `v`, `vn`, `g`, `f` lines; indices are 1-based (slot 0 of
+// vertices / normals is a dummy, :48-49); a face whose first vertex contains '/' is read as v/vt/vn; every
+// triangle becomes a SmoothTriangle.  Polygons are fanned over the FACE's own vertices; the reference fans
+// over the file-global vertices 1, k, k+1 (:101-116, :143-155), which coincides only for faces that are
+// literally `1 2 3 4 ...` -- ref_parser_quirk = true reproduces that.
+struct Wavefront {
+  std::vector<Vector4> vertices{Vector4::point(0, 0, 0)};
+  std::vector<Vector4> normals{Vector4::vector(0, 0, 0)};
+  std::vector<std::string> groups, comments;
+  std::vector<Shape> shapes;
+
+  static Wavefront parse(const std::string& path, bool ref_parser_quirk = false, std::optional<Material> material = {},
+                         std::optional<Matrix4> transformation = {}) {
+    std::ifstream in(path);
+    if (!in) throw Error(RT355_EINVAL, "cannot open " + path);
+    Wavefront w;
+    std::string line;
+    while (std::getline(in, line)) {
+      std::istringstream ls(line);
+      std::vector<std::string> words;
+      for (std::string t; ls >> t;) words.push_back(t);
+      if (words.empty() || words[0].size() > 2) {
+        w.comments.push_back(line);
+      } else if (words[0] == "v" && words.size() >= 4) {
+        w.vertices.push_back(Vector4::point(std::stof(words[1]), std::stof(words[2]), std::stof(words[3])));
+      } else if (words[0] == "vn" && words.size() >= 4) {
+        w.normals.push_back(Vector4::vector(std::stof(words[1]), std::stof(words[2]), std::stof(words[3])));
+      } else if (words[0] == "g") {
+        w.groups.push_back(line);
+      } else if (words[0] == "f") {
+        w.face(std::vector<std::string>(words.begin() + 1, words.end()), ref_parser_quirk, material, transformation);
+      } else {
+        w.comments.push_back(line);
+      }
+    }
+    return w;
+  }
+
+ private:
+  void face(const std::vector<std::string>& words, bool quirk, const std::optional<Material>& material, const std::optional<Matrix4>& transformation) {
+    if (words.size() < 3) return;
+    const bool with_normals = words[0].find('/') != std::string::npos;
+    const Vector4 zero = Vector4::vector(0, 0, 0);
+    std::vector<Vector4> vs, ns;
+    for (const std::string& word : words) {
+      if (with_normals) {
+        std::vector<std::string> f;
+        std::string part;
+        std::istringstream ws(word);
+        while (std::getline(ws, part, '/')) f.push_back(part);
+        if (f.size() < 3) throw Error(RT355_EINVAL, "face vertex without a normal index: " + word);
+        vs.push_back(vertices.at((size_t)std::stoi(f[0])));
+        ns.push_back(normals.at((size_t)std::stoi(f[2])));
+      } else {
+        vs.push_back(vertices.at((size_t)std::stoi(word)));
+        ns.push_back(zero);
+      }
+    }
+    const size_t l = vs.size();
+    auto emit = [&](Vector4 a, Vector4 b, Vector4 c, Vector4 na, Vector4 nb, Vector4 nc) {
+      shapes.push_back(Shape::smooth_triangle(transformation, material, a, b, c, na, nb, nc));
+    };
+    if (l == 3) {
+      emit(vs[0], vs[1], vs[2], ns[0], ns[1], ns[2]);
+    } else if (quirk) {
+      for (size_t index = 2; index < l; ++index)
+        emit(vertices.at(1), vertices.at(index), vertices.at(index + 1), with_normals ? normals.at(1) : zero,
+             with_normals ? normals.at(index) : zero, with_normals ? normals.at(index + 1) : zero);
+    } else {
+      for (size_t i = 1; i + 1 < l; ++i) emit(vs[0], vs[i], vs[i + 1], ns[0], ns[i], ns[i + 1]);
+    }
   }
 };
 

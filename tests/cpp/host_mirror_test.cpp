@@ -107,6 +107,67 @@ static void cpu_tests() {
   }
 }
 
+static bool same3(const Vector4& a, const Vector4& b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+
+// src/wavefront.rs:192-305 (fixtures: the reference's own small OBJ files) and src/group.rs:117-168
+static void loader_tests(const std::string& obj_dir) {
+  {
+    const Wavefront w = Wavefront::parse(obj_dir + "/vertex.obj");
+    CHECK(w.vertices.size() == 5 && same3(w.vertices[1], Vector4::point(-1, 1, 0)) && same3(w.vertices[2], Vector4::point(-1, 0.5f, 0)) &&
+          same3(w.vertices[3], Vector4::point(1, 0, 0)) && same3(w.vertices[4], Vector4::point(1, 1, 0)));
+  }
+  {
+    const Wavefront w = Wavefront::parse(obj_dir + "/face.obj");
+    CHECK(w.shapes.size() == 2 && w.shapes[0].kind == RT355_SMOOTH_TRIANGLE);
+    CHECK(same3(w.shapes[0].p1, w.vertices[1]) && same3(w.shapes[0].p2, w.vertices[2]) && same3(w.shapes[0].p3, w.vertices[3]));
+    CHECK(same3(w.shapes[1].p1, w.vertices[1]) && same3(w.shapes[1].p2, w.vertices[3]) && same3(w.shapes[1].p3, w.vertices[4]));
+  }
+  for (int quirk = 0; quirk < 2; ++quirk) {  // the face is `1 2 3 4 5`, where both fans coincide
+    const Wavefront w = Wavefront::parse(obj_dir + "/polygones.obj", quirk != 0);
+    CHECK(w.shapes.size() == 3);
+    const int idx[3][3] = {{1, 2, 3}, {1, 3, 4}, {1, 4, 5}};
+    for (size_t k = 0; k < 3 && k < w.shapes.size(); ++k)
+      CHECK(same3(w.shapes[k].p1, w.vertices[idx[k][0]]) && same3(w.shapes[k].p2, w.vertices[idx[k][1]]) && same3(w.shapes[k].p3, w.vertices[idx[k][2]]));
+  }
+  {
+    const Wavefront w = Wavefront::parse(obj_dir + "/vertex_normal.obj");
+    CHECK(w.normals.size() == 4 && same3(w.normals[1], Vector4::vector(0, 0, 1)) && same3(w.normals[2], Vector4::vector(0.707f, 0, -0.707f)) &&
+          same3(w.normals[3], Vector4::vector(1, 2, 3)));
+  }
+  {
+    const Wavefront w = Wavefront::parse(obj_dir + "/face_with_normal.obj");
+    CHECK(w.shapes.size() == 2);
+    for (const Shape& s : w.shapes)
+      CHECK(same3(s.p1, w.vertices[1]) && same3(s.p2, w.vertices[2]) && same3(s.p3, w.vertices[3]) && same3(s.n1, w.normals[3]) &&
+            same3(s.n2, w.normals[1]) && same3(s.n3, w.normals[2]));
+  }
+  {
+    bool threw = false;
+    try {
+      Wavefront::parse(obj_dir + "/no_such_file.obj");
+    } catch (const Error&) {
+      threw = true;
+    }
+    CHECK(threw);
+  }
+  // groups: one-level composition, depth-first order, inputs untouched
+  {
+    Node g1(Shape::group(Matrix4::rotation_y(PI / 2)));
+    Node& g2 = g1.add(Shape::group(Matrix4::scaling(2, 2, 2)));
+    g2.add(Shape::sphere(Matrix4::translation(5, 0, 0)));
+    const std::vector<Shape> flat = to_transformed_shapes(g1);
+    CHECK(flat.size() == 3 && flat[0].kind == RT355_GROUP && flat[1].kind == RT355_GROUP && flat[2].kind == RT355_SPHERE);
+    CHECK(near(flat[1].transformation, Matrix4::rotation_y(PI / 2) * Matrix4::scaling(2, 2, 2)));
+    CHECK(near(flat[2].transformation, Matrix4::scaling(2, 2, 2) * Matrix4::translation(5, 0, 0)));
+    const std::vector<Shape> acc = to_transformed_shapes(g1, true);
+    CHECK(near(acc[2].transformation, Matrix4::rotation_y(PI / 2) * Matrix4::scaling(2, 2, 2) * Matrix4::translation(5, 0, 0), 1e-4f));
+    Node root(Shape::sphere(Matrix4::scaling(3, 3, 3)));
+    root.add(Shape::cube(Matrix4::translation(1, 0, 0)));
+    const std::vector<Shape> pass = to_transformed_shapes(root);  // src/group.rs:154-166
+    CHECK(pass.size() == 2 && pass[1].kind == RT355_CUBE && near(pass[1].transformation, Matrix4::translation(1, 0, 0)));
+  }
+}
+
 static World ch9_world() {  // src/main.rs:202-273
   const Shape floor = Shape::plane({}, Material(Color::rgb(1.0f, 0.9f, 0.9f), {}, {}, {}, {}, {}, {}, {}, {}));
   const Shape middle = Shape::sphere(Matrix4::translation(-0.5f, 1.0f, 0.5f), Material(Color::rgb(1.0f, 0.2f, 0.2f), {}, {}, {}, {}, {}, {}, {}, {}));
@@ -168,8 +229,10 @@ int main(int argc, char** argv) {
   try {
     if (gpu)
       gpu_tests(argc > 2 ? argv[2] : nullptr);
-    else
+    else {
       cpu_tests();
+      if (argc > 2 && std::strcmp(argv[1], "--cpu") == 0) loader_tests(argv[2]);
+    }
   } catch (const std::exception& e) {
     std::printf("FAIL exception: %s\n", e.what());
     ++failures;

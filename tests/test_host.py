@@ -468,9 +468,9 @@ CPP_TEST = os.path.join(ROOT, "tests", "cpp", "host_mirror_test")
 
 
 def test_cpp_host_mirror_cpu_part():
-    """Matrix / view-transformation / camera / colour / PPM known answers of the reference and the ABI
-    records the C++ types fill, with no GPU."""
+    """Matrix / view-transformation / camera / colour / PPM known answers of the reference, the ABI records
+    the C++ types fill, the OBJ loader on the reference's fixtures and the group flattening, with no GPU."""
     assert os.path.exists(CPP_TEST), "run `python -c 'import __graft_entry__ as g; g.build()'` first"
-    r = subprocess.run([CPP_TEST, "--cpu"], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([CPP_TEST, "--cpu", OBJ], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "cpu: 0 failure(s)" in r.stdout
