@@ -200,6 +200,10 @@ int rt355_is_shadowed(rt355_ctx*, const rt355_scene*, const float* points, size_
 
 /* Color::to_u8 (src/color.rs:97-111) on the device: n floats -> n bytes, both HOST memory. */
 int rt355_to_u8(rt355_ctx*, const float* rgb, size_t n, uint8_t* out);
+/* The same with both buffers in DEVICE memory: a canvas left in HBM by rt355_render_device / rt355_untile
+ * becomes the bytes of a binary PPM body (src/ppm.rs:40-46 per pixel) without leaving the GPU, a quarter
+ * of the bytes to copy out.  Synchronous with respect to the host. */
+int rt355_to_u8_device(rt355_ctx*, const float* rgb_dev, size_t n, uint8_t* out_dev);
 
 /* Host only, needs no GPU: builds the scene tables and the BVH exactly as rt355_scene_upload does
  * (real_bits picks the box padding) and checks their structure: every bounded shape in exactly one

@@ -719,6 +719,17 @@ int rt355_to_u8(rt355_ctx* c, const float* rgb, size_t n, uint8_t* out) {
   return RT355_OK;
 }
 
+int rt355_to_u8_device(rt355_ctx* c, const float* rgb_dev, size_t n, uint8_t* out_dev) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if ((!rgb_dev || !out_dev) && n) return set_err(RT355_EINVAL, "null argument");
+  if (n == 0) return RT355_OK;
+  hipLaunchKernelGGL(k_to_u8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, rgb_dev, n, out_dev);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RT355_OK;
+}
+
 int rt355_scene_check(const rt355_shape_desc* shapes, size_t n_shapes, int real_bits, int exact_cones, uint64_t out[5]) {
   if ((!shapes && n_shapes) || !out) return set_err(RT355_EINVAL, "null argument");
   if (real_bits != 32 && real_bits != 64) return set_err(RT355_EINVAL, "real_bits must be 32 or 64");

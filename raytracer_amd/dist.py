@@ -101,3 +101,14 @@ def gather_canvas(local_tiles, width, height, rank, world_size, group=None, devi
         untile(device, camera, world_size, gathered.contiguous(), out)
         return out
     return torch.from_numpy(untile_host(gathered.numpy(), width, height, world_size))
+
+
+def canvas_to_u8(device, canvas):
+    """Color::to_u8 of a canvas that lives in HBM (CUDA float32 tensor) -> CUDA uint8 tensor of the same shape:
+    the body of a binary PPM, produced where the canvas is."""
+    import torch
+    assert canvas.is_cuda and canvas.is_contiguous() and canvas.dtype == torch.float32
+    torch.cuda.current_stream(canvas.device).synchronize()
+    out = torch.empty(canvas.shape, dtype=torch.uint8, device=canvas.device)
+    _abi.check(device.lib.rt355_to_u8_device(device.handle, C.c_void_p(canvas.data_ptr()), canvas.numel(), C.c_void_p(out.data_ptr())))
+    return out

@@ -491,3 +491,22 @@ def test_cpp_host_mirror_renders_like_the_python_one(tmp_path):
     d = np.abs(Color.to_u8(got).astype(int) - Color.to_u8(want).astype(int))
     assert (d.max(axis=2) > 1).mean() <= 0.001
     assert np.abs(got - want).max() < 0.05
+
+
+def test_canvas_to_u8_on_the_device(dev):
+    """rt355_to_u8_device on a canvas left in HBM equals Color::to_u8 (src/color.rs:97-111) on the host,
+    and gives the body of Canvas.to_ppm_p6."""
+    import torch
+    from raytracer_amd import dist as rd
+    from raytracer_amd.host import Canvas, Color
+    world, cam = scenes.ch9(70, 45)
+    scene = dev.upload(world)
+    canvas = torch.empty((45, 70, 3), dtype=torch.float32, device="cuda")
+    rd.render_canvas(scene, cam, 5, canvas.view(-1))
+    scene.close()
+    canvas[0, 0] = torch.tensor([float("nan"), -1.0, 7.0])  # NaN -> 0, clamps
+    got = rd.canvas_to_u8(dev, canvas).cpu().numpy()
+    host = canvas.cpu().numpy()
+    assert np.array_equal(got, Color.to_u8(host))
+    assert got[0, 0].tolist() == [0, 0, 255]
+    assert Canvas(70, 45, host).to_ppm_p6().endswith(got.tobytes())
