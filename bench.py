@@ -32,7 +32,7 @@ from raytracer_amd import dist as rd  # noqa: E402
 from raytracer_amd._abi import Stats  # noqa: E402
 
 FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 (FMA) x 2.4 GHz
-KIND_NAME = {1: "k_trace", 2: "k_shadow", 3: "k_combine", 5: "k_spawn"}
+KIND_NAME = {1: "k_trace", 2: "k_shadow", 3: "k_combine", 5: "k_spawn", 6: "k_scan"}
 
 
 def cpu_baseline(world, cam, depth):

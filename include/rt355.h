@@ -96,11 +96,12 @@ typedef struct rt355_camera_desc {
 
 /* Kernel classes recorded per launch in rt355_stats.launch_kind. */
 enum rt355_launch_kind {
-  RT355_K_TRACE = 1,     /* nearest-hit traversal of one generation, followed by the slot prefix sums */
+  RT355_K_TRACE = 1,     /* nearest-hit traversal of one generation; the deepest one also shades its hits */
   RT355_K_SHADE = 2,     /* shadow rays of one generation (is_shadowed)                              */
   RT355_K_COMBINE = 3,   /* Phong lighting + child colours folded into their parent; generation 0
                             writes the canvas */
-  RT355_K_SPAWN = 5      /* n1 / n2, reflect / refract / schlick: writes the rays of the next generation */
+  RT355_K_SPAWN = 5,     /* n1 / n2, reflect / refract / schlick: writes the rays of the next generation */
+  RT355_K_SCAN = 6       /* prefix sums of the child-ray slots of one generation (one block) */
 };
 
 /* Per-frame statistics.  Ray counts are always filled.  Work counters (box_tests ... flops) are

@@ -14,7 +14,7 @@ SPHERE, PLANE, CUBE, CYLINDER, CONE, GROUP, TRIANGLE, SMOOTH_TRIANGLE = range(8)
 # enum rt355_pattern (order of `enum Pattern`, src/pattern.rs:6-12; 0 = None)
 PATTERN_NONE, PATTERN_STRIPE, PATTERN_GRADIENT, PATTERN_RING, PATTERN_CHECKER, PATTERN_TEST = range(6)
 
-K_TRACE, K_SHADE, K_COMBINE, K_SPAWN = 1, 2, 3, 5
+K_TRACE, K_SHADE, K_COMBINE, K_SPAWN, K_SCAN = 1, 2, 3, 5, 6
 
 
 class MaterialDesc(C.Structure):

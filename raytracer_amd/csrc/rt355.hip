@@ -221,7 +221,9 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, uint32
     else
       hipLaunchKernelGGL((k_trace<R, COUNT, false, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n, cam, (g == 0 && primary) ? 1 : 0);
     log.n++;
+    if ((rc = rec(RT355_K_SCAN, g))) return rc;
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, pool.blk_hits, pool.blk_children, pool.blk_base, ctl, g, (long long)pool.capacity);
+    log.n++;
     if (g < depth) {  // the deepest generation spawns nothing
       if ((rc = rec(RT355_K_SPAWN, g))) return rc;
       // with the side stream in use, the event it waits for rides on this launch's own completion signal:

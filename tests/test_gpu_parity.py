@@ -344,7 +344,7 @@ def test_counting_mode_reports_work(dev):
     scene.close()
     assert np.array_equal(a, b)  # instrumented kernels compute the same image
     kinds = list(st.launch_kind[: st.n_launch])
-    assert kinds == [_abi.K_TRACE, _abi.K_COMBINE]  # one generation: traced and shaded in one launch
+    assert kinds == [_abi.K_TRACE, _abi.K_SCAN, _abi.K_COMBINE]  # one generation: traced and shaded in one launch
     assert st.launch_box_tests[0] > 0 and st.launch_prim_tests[0] > 0 and st.launch_flops[0] > 0
     assert all(st.launch_ms[i] >= 0 for i in range(st.n_launch))
 
