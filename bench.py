@@ -185,6 +185,9 @@ def main():
                           "gflop": round(float(flops[i]) / 1e9, 4), "max_box_tests_one_lane": int(maxbox[i]), "max_wave_clocks": int(st.launch_max_wave_clocks[i])} for i in range(len(kinds))],
             "rays_by_generation": rays_gen, "hits_by_generation": hits_gen,
         }
+        if traffic:
+            gbs = traffic / (ms_l[k] * 1e-3) / 1e9
+            out["roofline"]["hbm"] = {"achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4)}
         if not args.no_cpu_baseline and world_size == 1:
             out["cpu_baseline"] = cpu_baseline(world, cam, args.depth)
         print(json.dumps(out))
