@@ -1,5 +1,5 @@
 #!/bin/bash
-# One short bench line per survey configuration (run on the GPU box).  usage: scripts/configs.sh [real_bits]
+# One short bench line per benchmark configuration (run on the GPU box).  usage: scripts/configs.sh [real_bits]
 cd "$GRAFT_REPO_ROOT"
 real=${1:-64}
 run() {
