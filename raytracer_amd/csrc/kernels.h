@@ -1156,29 +1156,42 @@ RT_FN void write_pixel(const DevCamera<R>& cam, uint32_t i, int mode, float* out
   out[o] = (float)c.x, out[o + 1] = (float)c.y, out[o + 2] = (float)c.z;
 }
 
-template <class R>
+// Colour of ray r (World::color_at of the recursion below it), LEVELS generations of children deep: the
+// children's colours are evaluated on the way (LEVELS > 0) or taken as final from pool.color (LEVELS == 0).
+// The expression per hit is the one of src/world.rs:117-126, children first.
+template <class R, int LEVELS>
+RT_FN V3<R> ray_colour(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t r, bool has_children) {
+  const int p = pool.hit_prim[r];
+  if (p < 0) return V3<R>{R(0), R(0), R(0)};  // world.rs:61-63: a miss is black
+  const PrimInfo info = sc.prim_info[p];
+  const DevMaterial<R>& m = sc.materials[info.flags >> PF_MAT_SHIFT];
+  const V3<R> surface = ld3(pool.color + 3ull * r);  // left there by k_shadow
+  int32_t cr = -1, ct = -1;
+  R rs = R(-1);
+  if (has_children && (info.flags & (PF_REFLECTIVE | PF_TRANSPARENT))) cr = pool.child[2ull * r], ct = pool.child[2ull * r + 1], rs = pool.mixr[r];
+  V3<R> refl = {R(0), R(0), R(0)}, refr = {R(0), R(0), R(0)};
+  if constexpr (LEVELS > 0) {
+    // every generation walked here lies above the deepest one, so its hits may have children
+    if (cr >= 0) refl = ray_colour<R, LEVELS - 1>(sc, pool, (uint32_t)cr, true) * m.reflective;
+    if (ct >= 0) refr = ray_colour<R, LEVELS - 1>(sc, pool, (uint32_t)ct, true) * m.transparency;
+  } else {
+    if (cr >= 0) refl = ld3(pool.color + 3ull * cr) * m.reflective;
+    if (ct >= 0) refr = ld3(pool.color + 3ull * ct) * m.transparency;
+  }
+  if (rs >= R(0) || rs != rs) return surface + refl * rs + refr * (R(1) - rs);
+  return surface + refr + refl;
+}
+
+// LEVELS: how many generations below `gen` are folded in by walking each ray's own subtree (0: the children's
+// colours are final already).  With LEVELS = n the generations gen+1 .. gen+n need no launch of their own,
+// and generation gen+n+1 must be final (the deepest one, shaded inside its trace launch).
+template <class R, int LEVELS>
 __global__ void __launch_bounds__(256) k_combine(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int has_children, DevCamera<R> cam, int mode, float* out) {
   uint32_t start, gcount;
   gen_range(ctl, gen, pool.capacity, start, gcount);
   for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < gcount; i += gridDim.x * BLOCK) {
     const uint32_t r = start + i;
-    const int p = pool.hit_prim[r];
-    V3<R> c = {R(0), R(0), R(0)};  // world.rs:61-63: a miss is black
-    if (p >= 0) {
-      const PrimInfo info = sc.prim_info[p];
-      const DevMaterial<R>& m = sc.materials[info.flags >> PF_MAT_SHIFT];
-      const V3<R> surface = ld3(pool.color + 3ull * r);  // left there by k_shadow
-      int32_t cr = -1, ct = -1;
-      R rs = R(-1);
-      if (has_children && (info.flags & (PF_REFLECTIVE | PF_TRANSPARENT))) cr = pool.child[2ull * r], ct = pool.child[2ull * r + 1], rs = pool.mixr[r];
-      V3<R> refl = {R(0), R(0), R(0)}, refr = {R(0), R(0), R(0)};
-      if (cr >= 0) refl = ld3(pool.color + 3ull * cr) * m.reflective;
-      if (ct >= 0) refr = ld3(pool.color + 3ull * ct) * m.transparency;
-      if (rs >= R(0) || rs != rs)
-        c = surface + refl * rs + refr * (R(1) - rs);
-      else
-        c = surface + refr + refl;
-    }
+    const V3<R> c = ray_colour<R, LEVELS>(sc, pool, r, has_children != 0);
     if (gen > 0 || mode == OUT_NONE) st3(pool.color + 3ull * r, c);
     if (gen == 0 && mode != OUT_NONE) write_pixel(cam, i, mode, out, c);
   }

@@ -73,6 +73,7 @@ struct rt355_ctx {
   bool counting = false, timing = false;
   int exact_cones = 0;
   int packet_gens = 1;  // generations 0..packet_gens-1 use the wave-packet traversal (primary rays and their shadow rays)
+  int combine_levels = 2;  // generations folded into the first combine launch by walking ray subtrees (0..3)
   int shadow_lag = 0;   // the shadow launch of generation g is released behind the spawn of generation g + lag
   DevBuf org, dir, hit_t, hit_uv, hit_prim, color, mixr, child, blk_hits, blk_children, blk_base, ctl, io_in, io_out, io_out2;
   hipEvent_t ev[RT355_MAX_LAUNCH + 1] = {};  // timing mode: one before every launch, one behind the last
@@ -269,12 +270,23 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, uint32
     HIP_TRY(hipEventRecord(c->ev_side_done, c->side));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_side_done, 0));
   }
-  // the deepest generation's colours are final already; generation 0 still has to reach the canvas
-  for (int g = depth > 0 ? depth - 1 : 0; g >= 0; --g) {
+  // The deepest generation's colours are final already; generation 0 still has to reach the canvas.
+  // The generations right above the deepest one hold few rays, so one launch folds several of them: each
+  // ray of generation `top` walks its own subtree (at most 2^levels - 1 hits below it) instead of one
+  // latency-bound launch per generation.
+  const int levels = std::max(0, std::min(c->combine_levels, depth - 1));
+  const int top = depth > 0 ? depth - 1 - levels : 0;
+  for (int g = top; g >= 0; --g) {
     const uint32_t grid = g == 0 ? grid0 : std::min<uint32_t>(grid_cap, (uint32_t)((pool.capacity + BLOCK - 1) / BLOCK));
     int rc;
     if ((rc = rec(RT355_K_COMBINE, g))) return rc;
-    hipLaunchKernelGGL((k_combine<R>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, g < depth ? 1 : 0, cam, out_mode, out_dev);
+    const int has_children = g < depth ? 1 : 0;
+    switch (g == top ? levels : 0) {
+      case 3: hipLaunchKernelGGL((k_combine<R, 3>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, has_children, cam, out_mode, out_dev); break;
+      case 2: hipLaunchKernelGGL((k_combine<R, 2>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, has_children, cam, out_mode, out_dev); break;
+      case 1: hipLaunchKernelGGL((k_combine<R, 1>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, has_children, cam, out_mode, out_dev); break;
+      default: hipLaunchKernelGGL((k_combine<R, 0>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, has_children, cam, out_mode, out_dev); break;
+    }
     log.n++;
   }
   if (c->timing && log.n <= RT355_MAX_LAUNCH) HIP_TRY(hipEventRecord(c->ev[log.n], c->stream));
@@ -524,6 +536,7 @@ int rt355_ctx_create(rt355_ctx** out, int device_id, int real_bits) {
     return set_err(RT355_ENOMEM, "pinned host allocation failed");
   }
   if (const char* e = getenv("RT355_PACKET_GENS")) c->packet_gens = atoi(e);
+  if (const char* e = getenv("RT355_COMBINE_LEVELS")) c->combine_levels = std::max(0, std::min(3, atoi(e)));
   if (const char* e = getenv("RT355_SHADOW_LAG")) c->shadow_lag = std::max(0, atoi(e));
   *out = c;
   return RT355_OK;
