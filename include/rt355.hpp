@@ -370,9 +370,10 @@ struct Wavefront {
         std::string part;
         std::istringstream ws(word);
         while (std::getline(ws, part, '/')) f.push_back(part);
-        if (f.size() < 3) throw Error(RT355_EINVAL, "face vertex without a normal index: " + word);
-        vs.push_back(vertices.at((size_t)std::stoi(f[0])));
-        ns.push_back(normals.at((size_t)std::stoi(f[2])));
+        // `v/vt` (no normal index) is read as a vertex without a normal; the reference indexes f[2]
+        // unconditionally (src/wavefront.rs:93) and panics on such a file
+        vs.push_back(vertices.at((size_t)std::stoi(f.at(0))));
+        ns.push_back(f.size() >= 3 && !f[2].empty() ? normals.at((size_t)std::stoi(f[2])) : zero);
       } else {
         vs.push_back(vertices.at((size_t)std::stoi(word)));
         ns.push_back(zero);

@@ -69,16 +69,16 @@ def render(world, camera, depth=5, real_bits=32, flags=0, window=None, threads=1
     return out, counters, sec.value
 
 
-def color_at(world, rays, depth=5, real_bits=32, flags=0):
+def color_at(world, rays, depth=5, real_bits=32, flags=0, threads=1):
     descs, n, light = _world_args(world)
     r = _f32(rays, 6)
     out = np.zeros((r.shape[0], 3), dtype=np.float64)
-    rc = lib().rto_color_at(descs, n, C.byref(light), _p(r), C.c_size_t(r.shape[0]), depth, real_bits, flags, _p(out))
+    rc = lib().rto_color_at(descs, n, C.byref(light), _p(r), C.c_size_t(r.shape[0]), depth, real_bits, flags, threads, _p(out))
     assert rc == 0
     return out
 
 
-def hit(world, rays, real_bits=32, with_beyond=False):
+def hit(world, rays, real_bits=32, with_beyond=False, threads=1):
     """Nearest hit per ray: (t float64 [NaN = miss], shape index int32 [-1 = miss], gap to the nearest
     intersection of another shape[, flag: truncated-cone hit outside its extent])."""
     descs, n, _ = _world_args(world)
@@ -87,7 +87,7 @@ def hit(world, rays, real_bits=32, with_beyond=False):
     idx = np.zeros(r.shape[0], dtype=np.int32)
     gap = np.zeros(r.shape[0], dtype=np.float64)
     beyond = np.zeros(r.shape[0], dtype=np.uint8)
-    rc = lib().rto_hit(descs, n, _p(r), C.c_size_t(r.shape[0]), real_bits, _p(t), _p(idx), _p(gap), _p(beyond))
+    rc = lib().rto_hit(descs, n, _p(r), C.c_size_t(r.shape[0]), real_bits, threads, _p(t), _p(idx), _p(gap), _p(beyond))
     assert rc == 0
     if with_beyond:
         return t, idx, gap, beyond.astype(bool)
@@ -155,11 +155,11 @@ def lighting(material, light, point, eyev, normalv, shadowed, real_bits=32):
     return out
 
 
-def is_shadowed(world, points, real_bits=32):
+def is_shadowed(world, points, real_bits=32, threads=1):
     descs, n, light = _world_args(world)
     p = _f32(points, 3)
     out = np.zeros(p.shape[0], dtype=np.uint8)
-    rc = lib().rto_is_shadowed(descs, n, C.byref(light), _p(p), C.c_size_t(p.shape[0]), real_bits, _p(out))
+    rc = lib().rto_is_shadowed(descs, n, C.byref(light), _p(p), C.c_size_t(p.shape[0]), real_bits, threads, _p(out))
     assert rc == 0
     return out.astype(bool)
 

@@ -31,6 +31,27 @@ bool build_world(const rt355_shape_desc* shapes, size_t n, const rt355_light_des
   return true;
 }
 
+// Runs body(i) for i in [0, n) on nthreads host threads (work handed out in blocks of 64 indices).  The rays /
+// points of one call are independent, exactly as the pixels of Camera::render are (camera.rs:76-82).
+template <class F>
+void parallel_for(size_t n, int nthreads, F&& body) {
+  if (nthreads <= 1 || n < 128) {
+    for (size_t i = 0; i < n; ++i) body(i);
+    return;
+  }
+  std::atomic<size_t> next(0);
+  auto worker = [&]() {
+    for (;;) {
+      const size_t b = next.fetch_add(64);
+      if (b >= n) break;
+      for (size_t i = b; i < std::min(n, b + 64); ++i) body(i);
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; ++t) th.emplace_back(worker);
+  for (auto& t : th) t.join();
+}
+
 template <class R>
 int render_impl(const rt355_shape_desc* shapes, size_t n, const rt355_light_desc* light,
                 const rt355_camera_desc* cam, int depth, int flags, int x0, int x1, int y0, int y1,
@@ -81,24 +102,24 @@ int render_impl(const rt355_shape_desc* shapes, size_t n, const rt355_light_desc
 
 template <class R>
 int color_at_impl(const rt355_shape_desc* shapes, size_t n, const rt355_light_desc* light,
-                  const float* rays, size_t nrays, int depth, int flags, double* rgb_out) {
+                  const float* rays, size_t nrays, int depth, int flags, int nthreads, double* rgb_out) {
   World<R> w;
   if (!build_world<R>(shapes, n, light, flags, w)) return -1;
-  for (size_t i = 0; i < nrays; ++i) {
+  parallel_for(nrays, nthreads, [&](size_t i) {
     const float* r = rays + i * 6;
     Ray<R> ray{point<R>(r[0], r[1], r[2]), vec<R>(r[3], r[4], r[5])};
     Color<R> c = w.color_at(ray, depth, depth, nullptr);
     rgb_out[i * 3 + 0] = c.r, rgb_out[i * 3 + 1] = c.g, rgb_out[i * 3 + 2] = c.b;
-  }
+  });
   return 0;
 }
 
 template <class R>
-int hit_impl(const rt355_shape_desc* shapes, size_t n, const float* rays, size_t nrays, double* t_out,
+int hit_impl(const rt355_shape_desc* shapes, size_t n, const float* rays, size_t nrays, int nthreads, double* t_out,
              int32_t* idx_out, double* runner_up_gap, uint8_t* beyond_extent) {
   World<R> w;
   if (!build_world<R>(shapes, n, nullptr, 0, w)) return -1;
-  for (size_t i = 0; i < nrays; ++i) {
+  parallel_for(nrays, nthreads, [&](size_t i) {
     const float* r = rays + i * 6;
     Ray<R> ray{point<R>(r[0], r[1], r[2]), vec<R>(r[3], r[4], r[5])};
     auto xs = w.intersect(ray);
@@ -108,7 +129,7 @@ int hit_impl(const rt355_shape_desc* shapes, size_t n, const float* rays, size_t
       idx_out[i] = -1;
       if (runner_up_gap) runner_up_gap[i] = std::numeric_limits<double>::infinity();
       if (beyond_extent) beyond_extent[i] = 0;
-      continue;
+      return;
     }
     t_out[i] = xs[h].t;
     idx_out[i] = xs[h].shape;
@@ -128,7 +149,7 @@ int hit_impl(const rt355_shape_desc* shapes, size_t n, const float* rays, size_t
         if (x.t >= R(0) && x.shape != xs[h].shape) gap = std::min(gap, std::fabs((double)x.t - (double)xs[h].t));
       runner_up_gap[i] = gap;
     }
-  }
+  });
   return 0;
 }
 
@@ -216,10 +237,10 @@ int lighting_impl(const rt355_material* m, const rt355_light_desc* light, const 
 
 template <class R>
 int shadowed_impl(const rt355_shape_desc* shapes, size_t n, const rt355_light_desc* light, const float* pts,
-                  size_t npts, uint8_t* out) {
+                  size_t npts, int nthreads, uint8_t* out) {
   World<R> w;
   if (!build_world<R>(shapes, n, light, 0, w)) return -1;
-  for (size_t i = 0; i < npts; ++i) out[i] = w.is_shadowed(point<R>(pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2])) ? 1 : 0;
+  parallel_for(npts, nthreads, [&](size_t i) { out[i] = w.is_shadowed(point<R>(pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2])) ? 1 : 0; });
   return 0;
 }
 
@@ -252,12 +273,12 @@ int rto_render(const rt355_shape_desc* shapes, size_t n, const rt355_light_desc*
   return DISPATCH(real_bits, render_impl, shapes, n, light, cam, depth, flags, x0, x1, y0, y1, nthreads, rgb_out, counters, seconds);
 }
 int rto_color_at(const rt355_shape_desc* shapes, size_t n, const rt355_light_desc* light, const float* rays,
-                 size_t nrays, int depth, int real_bits, int flags, double* rgb_out) {
-  return DISPATCH(real_bits, color_at_impl, shapes, n, light, rays, nrays, depth, flags, rgb_out);
+                 size_t nrays, int depth, int real_bits, int flags, int nthreads, double* rgb_out) {
+  return DISPATCH(real_bits, color_at_impl, shapes, n, light, rays, nrays, depth, flags, nthreads, rgb_out);
 }
-int rto_hit(const rt355_shape_desc* shapes, size_t n, const float* rays, size_t nrays, int real_bits,
+int rto_hit(const rt355_shape_desc* shapes, size_t n, const float* rays, size_t nrays, int real_bits, int nthreads,
             double* t_out, int32_t* idx_out, double* runner_up_gap, uint8_t* beyond_extent) {
-  return DISPATCH(real_bits, hit_impl, shapes, n, rays, nrays, t_out, idx_out, runner_up_gap, beyond_extent);
+  return DISPATCH(real_bits, hit_impl, shapes, n, rays, nrays, nthreads, t_out, idx_out, runner_up_gap, beyond_extent);
 }
 int rto_world_intersect(const rt355_shape_desc* shapes, size_t n, const float* ray, int real_bits,
                         double* t_out, int32_t* idx_out, int cap) {
@@ -284,8 +305,8 @@ int rto_lighting(const rt355_material* m, const rt355_light_desc* light, const f
   return DISPATCH(real_bits, lighting_impl, m, light, p, eyev, normalv, shadowed, rgb);
 }
 int rto_is_shadowed(const rt355_shape_desc* shapes, size_t n, const rt355_light_desc* light, const float* pts,
-                    size_t npts, int real_bits, uint8_t* out) {
-  return DISPATCH(real_bits, shadowed_impl, shapes, n, light, pts, npts, out);
+                    size_t npts, int real_bits, int nthreads, uint8_t* out) {
+  return DISPATCH(real_bits, shadowed_impl, shapes, n, light, pts, npts, nthreads, out);
 }
 int rto_camera_rays(const rt355_camera_desc* cam, const float* pxy, size_t n, int real_bits, double* rays_out,
                     double* pixel_size) {

@@ -951,7 +951,10 @@ RT_FN void container_indices(const DevScene<R>& sc, bool need, int p, PrimInfo i
   const bool others_unit = (info.flags & PF_OTHERS_UNIT) != 0;
   const R floor_t = (others_unit && h_before) ? hmt : -inf<R>();
   const int floor_s = (others_unit && h_before) ? info.shape : -1;
-  const V3<R> rd = R(-1) * d;
+  // Reversed ray.  A zero component keeps its sign: the cube's slab test branches on d >= 0
+  // (src/shape.rs:455-466), which -0.0 passes, so flipping the sign of a zero would turn a slab the forward
+  // ray lies inside into a miss, and the reversed ray would no longer see the forward ray's intersections.
+  const V3<R> rd = {d.x == R(0) ? d.x : -d.x, d.y == R(0) ? d.y : -d.y, d.z == R(0) ? d.z : -d.z};
   bool searching = need && !(others_unit && !h_before), found = false;
   int other_flags = 0, other_s = -1;
   R other_t = R(0);
@@ -1064,7 +1067,7 @@ __global__ void __launch_bounds__(256, 3) k_spawn(DevScene<R> sc, RayPool<R> poo
           refr_d = (n_ratio * cos_ti - cos_t) * c.normalv - n_ratio * c.eyev;
           want_refr = true;
         }
-        if (slot_r) {  // reflective > 0 && transparency > 0 (materials are non-negative): schlick()
+        if (info.flags & PF_SCHLICK) {  // reflective > 0 && transparency > 0 (src/world.rs:120): schlick()
           R cs = cos_ti;
           bool tir = false;
           if (n1 > n2) {

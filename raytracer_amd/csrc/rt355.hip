@@ -109,12 +109,25 @@ DevScene<R> dev_scene(const rt355_scene* s) {
   return d;
 }
 
+// hsize / vsize as the integers the reference keeps them in (usize, src/camera.rs:12-13).  Checked before
+// any cast or allocation: NaN, infinities, sizes below 1 or beyond what a canvas can be are rejected.
+constexpr float MAX_CANVAS_EDGE = 65536.f;
+int camera_dims(const rt355_camera_desc* c, int& w, int& h) {
+  if (!c) return set_err(RT355_EINVAL, "null camera");
+  if (!std::isfinite(c->hsize) || !std::isfinite(c->vsize) || !(c->hsize >= 1.f) || !(c->vsize >= 1.f) || c->hsize > MAX_CANVAS_EDGE ||
+      c->vsize > MAX_CANVAS_EDGE)
+    return set_err(RT355_EINVAL, "camera: hsize and vsize must be finite and in [1, 65536]");
+  w = (int)c->hsize, h = (int)c->vsize;
+  return RT355_OK;
+}
+
 // Camera::new (src/camera.rs:23-51) in R, plus the inverse of the camera transformation that
 // ray_for_pixel recomputes per pixel (src/camera.rs:67).
 template <class R>
 int dev_camera(const rt355_camera_desc* c, int rank, int n_ranks, DevCamera<R>& out) {
-  if (!(c->hsize >= 1.f) || !(c->vsize >= 1.f) || !std::isfinite(c->hsize) || !std::isfinite(c->vsize) || !std::isfinite(c->fov))
-    return set_err(RT355_EINVAL, "camera: bad size or field of view");
+  int cw = 0, chh = 0;
+  if (int rc = camera_dims(c, cw, chh)) return rc;
+  if (!std::isfinite(c->fov)) return set_err(RT355_EINVAL, "camera: bad field of view");
   const float* m = c->transform;
   for (int k = 0; k < 16; ++k)
     if (!std::isfinite(m[k])) return set_err(RT355_EINVAL, "camera: non-finite transformation");
@@ -140,7 +153,7 @@ int dev_camera(const rt355_camera_desc* c, int rank, int n_ranks, DevCamera<R>& 
   out.half_width = aspect >= R(1) ? half_view : half_view * aspect;
   out.half_height = aspect >= R(1) ? half_view / aspect : half_view;
   out.pixel_size = (out.half_width * R(2)) / hsize;
-  out.width = (int)c->hsize, out.height = (int)c->vsize;
+  out.width = cw, out.height = chh;
   out.tiles_x = (out.width + TILE - 1) / TILE, out.tiles_y = (out.height + TILE - 1) / TILE;
   out.n_tiles = out.tiles_x * out.tiles_y;
   out.rank = rank, out.n_ranks = n_ranks;
@@ -445,6 +458,7 @@ int upload_impl(rt355_ctx* c, const HostScene& hs, rt355_scene* s) {
     info[i].flags = p.flags | (p.material << PF_MAT_SHIFT);
     if (hs.materials[p.material].reflective != 0.f) info[i].flags |= PF_REFLECTIVE;
     if (hs.materials[p.material].transparency != 0.f) info[i].flags |= PF_TRANSPARENT;
+    if (hs.materials[p.material].reflective > 0.f && hs.materials[p.material].transparency > 0.f) info[i].flags |= PF_SCHLICK;
     for (int k = 0; k < 12; ++k) xf[i].r[k] = (R)p.inv[k];
     xf[i].ymin = (R)p.ymin, xf[i].ymax = (R)p.ymax, xf[i].pad0 = xf[i].pad1 = 0;
     if ((p.flags & PF_KIND_MASK) >= RT355_TRIANGLE) any_tri = true;
@@ -535,7 +549,7 @@ int rt355_ctx_create(rt355_ctx** out, int device_id, int real_bits) {
     rt355_ctx_destroy(c);
     return set_err(RT355_ENOMEM, "pinned host allocation failed");
   }
-  if (const char* e = getenv("RT355_PACKET_GENS")) c->packet_gens = atoi(e);
+  if (const char* e = getenv("RT355_PACKET_GENS")) c->packet_gens = std::max(0, std::min((int)RT355_MAX_GEN, atoi(e)));
   if (const char* e = getenv("RT355_COMBINE_LEVELS")) c->combine_levels = std::max(0, std::min(3, atoi(e)));
   if (const char* e = getenv("RT355_SHADOW_LAG")) c->shadow_lag = std::max(0, atoi(e));
   *out = c;
@@ -621,8 +635,9 @@ int rt355_scene_info(const rt355_scene* s, uint64_t out[5]) {
 }
 
 int64_t rt355_tiles_per_rank(const rt355_camera_desc* cam, int n_ranks) {
-  if (!cam || n_ranks < 1) return -1;
-  return tiles_per_rank_of((int)cam->hsize, (int)cam->vsize, n_ranks);
+  int w = 0, h = 0;
+  if (n_ranks < 1 || camera_dims(cam, w, h)) return -1;
+  return tiles_per_rank_of(w, h, n_ranks);
 }
 
 static int check_render_args(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam, int max_depth) {
@@ -631,7 +646,8 @@ static int check_render_args(rt355_ctx* c, const rt355_scene* s, const rt355_cam
   if (!s || !cam) return set_err(RT355_EINVAL, "null argument");
   if (s->ctx != c) return set_err(RT355_EINVAL, "scene belongs to another context");
   if (max_depth < 0 || max_depth >= RT355_MAX_GEN) return set_err(RT355_EINVAL, "max_depth must be in [0,7]");
-  return RT355_OK;
+  int w = 0, h = 0;
+  return camera_dims(cam, w, h);
 }
 
 int rt355_render(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam, int max_depth, float* rgb_out, rt355_stats* stats) {
@@ -669,8 +685,8 @@ int rt355_untile(rt355_ctx* c, const rt355_camera_desc* cam, int n_ranks, const 
   int rc = check_ctx(c);
   if (rc) return rc;
   if (!cam || !gathered_dev || !rgb_out_dev || n_ranks < 1) return set_err(RT355_EINVAL, "bad argument");
-  const int w = (int)cam->hsize, h = (int)cam->vsize;
-  if (w < 1 || h < 1) return set_err(RT355_EINVAL, "bad canvas size");
+  int w = 0, h = 0;
+  if ((rc = camera_dims(cam, w, h))) return rc;
   const int tiles_x = (w + TILE - 1) / TILE, tiles_y = (h + TILE - 1) / TILE;
   const long long total = (long long)w * h;
   hipLaunchKernelGGL(k_untile, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, gathered_dev, rgb_out_dev, w, h, tiles_x,

@@ -34,7 +34,8 @@ constexpr int PF_IDENTITY = 16;  // transformation is exactly the identity: the 
 constexpr int PF_REFLECTIVE = 32;   // material.reflective != 0: a hit may spawn a reflected ray
 constexpr int PF_TRANSPARENT = 64;  // material.transparency != 0: a hit may spawn a refracted ray
 constexpr int PF_OTHERS_UNIT = 128;  // every OTHER prim of the scene has refractive index 1: n1 / n2 need less searching
-constexpr int PF_MAT_SHIFT = 8;
+constexpr int PF_SCHLICK = 256;      // reflective > 0 && transparency > 0: the two child colours are mixed by schlick()
+constexpr int PF_MAT_SHIFT = 9;
 
 struct PrimInfo {
   int32_t shape;  // index in World.shapes

@@ -131,7 +131,8 @@ struct Builder {
       return id;
     };
     if (count <= 1) return make_leaf();
-    static const int leaf_max = getenv("RT355_LEAF_MAX") ? atoi(getenv("RT355_LEAF_MAX")) : LEAF_MAX;
+    // the leaf reference keeps the count in 5 bits (and bit 31 must stay clear): clamp what the environment asks for
+    static const int leaf_max = getenv("RT355_LEAF_MAX") ? std::max(1, std::min(31, atoi(getenv("RT355_LEAF_MAX")))) : LEAF_MAX;
     static const double trav_cost = getenv("RT355_TRAV_COST") ? atof(getenv("RT355_TRAV_COST")) : 4.0;
     bool must_split = count > leaf_max;
     if (depth >= MAX_TREE_DEPTH - 1 && count <= 31) return make_leaf();  // leaf count field is 5 bits
@@ -322,7 +323,7 @@ int build_host_scene(const rt355_shape_desc* shapes, size_t n, double pad_rel, i
       unbounded.push_back(p);
     }
   }
-  if (out.materials.size() >= (1u << 23)) {
+  if (out.materials.size() >= (1u << 22)) {
     snprintf(err, errlen, "too many distinct materials");
     return RT355_EINVAL;
   }

@@ -52,7 +52,9 @@ class Wavefront:
             if with_normals:
                 f = word.split("/")
                 vs.append(self.vertices[int(f[0])])
-                ns.append(self.normals[int(f[2])])
+                # `v/vt` (no normal index) is read as a vertex without a normal; the reference indexes f[2]
+                # unconditionally (src/wavefront.rs:93) and panics on such a file
+                ns.append(self.normals[int(f[2])] if len(f) >= 3 and f[2] else (0.0, 0.0, 0.0))
             else:
                 vs.append(self.vertices[int(word)])
                 ns.append((0.0, 0.0, 0.0))

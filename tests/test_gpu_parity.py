@@ -196,11 +196,11 @@ def test_trace_ties_lowest_index_wins(dev):
 # ch11 (src/main.rs:389-535) is ill-conditioned by construction: its floor is a sphere squashed to 0.01
 # (thinner than 10 * EPSILON) and its walls are rotated planes whose untransformed normal (src/shape.rs:144)
 # leaves over_point ON the wall, so the shadow test there is decided by the last bit.  In float the
-# reference's own image is rounding noise in those regions and cannot be matched pixel by pixel; the
-# float bar for it only guards against gross errors.
+# reference's own image is rounding noise in those regions: its float bar (None) is the masked comparison of
+# test_gpu_configs.py::test_ch11_f32_outside_the_ill_conditioned_pixels, not a whole-image fraction.
 IMAGES = [
     ("ch9", lambda: scenes.ch9(200, 150), 0.002, 0.002),
-    ("ch11", lambda: scenes.ch11(160, 120), 0.004, 0.6),
+    ("ch11", lambda: scenes.ch11(160, 120), 0.004, None),
     ("glass", lambda: scenes.glass(160, 120), 0.004, 0.01),
     ("teapot_low", lambda: scenes.teapot_low(160, 90), 0.002, 0.004),
     ("north_star_low", lambda: scenes.north_star(128, 72, mesh="teapot-low.obj"), 0.004, 0.01),
@@ -211,6 +211,8 @@ IMAGES = [
 @pytest.mark.parametrize("name,build,tol64,tol32", IMAGES, ids=[i[0] for i in IMAGES])
 def test_image_parity(oracle, dev, name, build, tol64, tol32):
     tol = tol64 if dev.real_bits == 64 else tol32
+    if tol is None:
+        pytest.skip("compared under a mask of the ill-conditioned pixels in test_gpu_configs.py")
     world, cam = build()
     scene = dev.upload(world)
     st = Stats()
@@ -222,12 +224,15 @@ def test_image_parity(oracle, dev, name, build, tol64, tol32):
     frac = mismatch(oracle.to_u8(got), oracle.to_u8(want))
     print(f"{name} real={dev.real_bits}: mismatching pixels {frac:.5%}, rays {int(st.total_radiance)} + {int(st.total_shadow)} shadow")
     assert frac <= tol
-    # ray counts: identical unless a mismatching pixel changed the ray tree
+    # ray counts: identical unless a pixel's ray tree changed (a mismatching pixel can move its whole tree
+    # of at most 63 rays; a grazing deep ray of small weight can flip without moving the pixel by 1/255)
     tot_o = int(cnt["radiance"].sum())
     # generation 0 of the device includes tile padding pixels
     w, h = int(cam.horizontal_size), int(cam.vertical_size)
     dev_radiance = int(st.total_radiance) - int(st.radiance_rays[0]) + w * h
-    slack = max(8, (0.01 + 4 * tol) * tot_o)
+    n_bad = int(round(frac * w * h))
+    slack = 8 + 64 * n_bad + (0.0005 if dev.real_bits == 64 else 0.01) * tot_o
+    print(f"{name} real={dev.real_bits}: radiance rays {dev_radiance} vs {tot_o}, shadow rays {int(st.total_shadow)} vs {int(cnt['hits'].sum())}")
     assert abs(dev_radiance - tot_o) <= slack
     assert abs(int(st.total_shadow) - int(cnt["hits"].sum())) <= slack
 
@@ -243,15 +248,27 @@ def test_image_f64_device_vs_f32_oracle_reported(oracle):
     assert frac <= 0.005
 
 
-def test_counts_exact_on_simple_scene(oracle, dev):
-    world, cam = scenes.ch9(96, 64)  # 96x64: whole tiles, no padding
+@pytest.mark.parametrize("name", ["ch9", "glass", "north_star_low"])
+def test_counts_exact_on_small_scenes(oracle, dev, name):
+    """Radiance rays and hits (= shadow rays) per generation equal the oracle's counters exactly in f64 on
+    the small parity scenes (96x64: whole tiles, no padding); in f32 the two sides round differently
+    (contracted FMAs on the device) and a handful of grazing rays may flip."""
+    build = {"ch9": scenes.ch9, "glass": scenes.glass, "north_star_low": lambda w, h: scenes.north_star(w, h, mesh="teapot-low.obj")}[name]
+    world, cam = build(96, 64)
     scene = dev.upload(world)
     st = Stats()
     scene.render(cam, 5, st)
     scene.close()
-    _, cnt, _ = oracle.render(world, cam, 5, dev.real_bits)
-    assert int(st.radiance_rays[0]) == 96 * 64 == int(cnt["radiance"][0])
-    assert abs(int(st.hits[0]) - int(cnt["hits"][0])) <= 2
+    _, cnt, _ = oracle.render(world, cam, 5, dev.real_bits, threads=8)
+    got_r, got_h = [int(x) for x in st.radiance_rays], [int(x) for x in st.hits]
+    want_r, want_h = [int(x) for x in cnt["radiance"]], [int(x) for x in cnt["hits"]]
+    print(f"{name} real={dev.real_bits}: rays {got_r} vs {want_r}; hits {got_h} vs {want_h}")
+    assert got_r[0] == 96 * 64 == want_r[0]
+    if dev.real_bits == 64:
+        assert got_r == want_r and got_h == want_h
+    else:
+        assert sum(abs(a - b) for a, b in zip(got_r, want_r)) <= 0.003 * sum(want_r)
+        assert sum(abs(a - b) for a, b in zip(got_h, want_h)) <= 0.003 * sum(want_h)
 
 
 # ---------------------------------------------------------------- tiles / multi-rank layout
@@ -513,8 +530,9 @@ def test_canvas_to_u8_on_the_device(dev):
     assert Canvas(70, 45, host).to_ppm_p6().endswith(got.tobytes())
 
 
-def test_largest_configured_frame(oracle):
-    """7680x4320, the largest frame of the configurations (33 M primary rays, a 31 GB ray pool in f64):
+def test_glass_scene_at_8k(oracle):
+    """The glass scene at 7680x4320, the largest frame size of the configurations (33 M primary rays, a 31 GB
+    ray pool in f64; the stress scene of that configuration is rendered at this size in test_gpu_configs.py):
     the 8-rank tile split reassembles to the frame rendered in one piece, bit for bit, and a few pixels
     agree with the oracle."""
     import torch

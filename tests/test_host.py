@@ -208,6 +208,18 @@ def test_fan_over_the_face_not_the_file():
         ((0, 0, 0), (9, 9, 9), (1, 0, 0)), ((0, 0, 0), (1, 0, 0), (1, 1, 0))]
 
 
+def test_face_index_forms():
+    """`v//vn` and `v/vt/vn` carry a normal index; `v/vt` does not (the reference panics on it,
+    src/wavefront.rs:93) and is read as a vertex without a normal."""
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "f.obj")
+        open(path, "w").write("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 3//1\nf 1/7/1 2/8/1 3/9/1\nf 1/7 2/8 3/9\n")
+        w = Wavefront.parse(path)
+    assert len(w.shapes) == 3
+    assert [_p(w.shapes[k], "n1") for k in range(3)] == [(0, 0, 1), (0, 0, 1), (0, 0, 0)]
+    assert all(_p(s, "p2") == (1, 0, 0) for s in w.shapes)
+
+
 def test_teapots_have_the_expected_triangle_counts():
     assets = os.path.join(ROOT, "raytracer_amd", "assets")
     assert len(Wavefront.parse(os.path.join(assets, "teapot-low.obj")).shapes) == 240
