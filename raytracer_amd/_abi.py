@@ -77,7 +77,8 @@ class Stats(C.Structure):
     ]
 
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "librt355.so")
+# RT355_LIB: another build of the same library (kernel experiments); the default is the in-tree build
+LIB_PATH = os.environ.get("RT355_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "librt355.so")
 
 # (name, restype, argtypes): every symbol include/rt355.h declares
 SYMBOLS = [

@@ -71,9 +71,42 @@ template <class R> RT_FN V3<R> xf_vec(const R* r, V3<R> v) {
           r[8] * v.x + r[9] * v.y + r[10] * v.z};
 }
 
+#ifdef RT355_EXP_STAMPS
+struct DbgAcc {
+  unsigned long long cyc_node = 0, cyc_tri = 0, cyc_prim = 0;
+  uint32_t trips = 0, n_node = 0, n_leaf = 0;
+};
+#endif
 struct Work {  // per-thread work counters (counting mode only)
   uint32_t box = 0, xf = 0, prim[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef RT355_EXP_STAMPS
+  DbgAcc dbg;  // of the traversal in flight
+#endif
 };
+#ifdef RT355_EXP_STAMPS
+// Diagnostic build only: one record per (launch, block, wave), summed over the wave's trips: 100 MHz wall
+// clock of its first traversal start and last traversal end, shader cycles spent in node steps, triangle
+// leaves and other leaves, loop trips of the wave.
+struct DbgRec {
+  unsigned long long t0, t1;
+  unsigned long long cyc_node, cyc_tri, cyc_prim, cyc_total;
+  uint32_t trips, lanes, n_node, n_leaf;
+};
+constexpr uint32_t DBG_PER_LAUNCH = 1u << 15;
+__device__ DbgRec g_dbg[RT355_MAX_LAUNCH * DBG_PER_LAUNCH];
+RT_FN void dbg_record(int launch, unsigned long long t0, unsigned long long c0, const DbgAcc& a, bool live) {
+  const unsigned long long t1 = wall_clock64(), c1 = __builtin_amdgcn_s_memtime();
+  const uint32_t lanes = __popcll(__ballot(live));
+  if ((threadIdx.x & 63u) == 0 && launch < RT355_MAX_LAUNCH) {
+    const uint32_t slot = (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) & (DBG_PER_LAUNCH - 1);
+    DbgRec& r = g_dbg[(size_t)launch * DBG_PER_LAUNCH + slot];
+    if (r.trips == 0) r.t0 = t0;
+    r.t1 = t1;
+    r.cyc_node += a.cyc_node, r.cyc_tri += a.cyc_tri, r.cyc_prim += a.cyc_prim, r.cyc_total += c1 - c0;
+    r.trips += a.trips, r.lanes += lanes, r.n_node += a.n_node, r.n_leaf += a.n_leaf;
+  }
+}
+#endif
 // Counters of one thread -> FrameCtl.  Reduced over the wave first (every lane of the wave calls this at
 // the end of its kernel), so the per-launch totals cost 11 atomics per wave, not per lane.
 template <bool COUNT> RT_FN void flush_work(FrameCtl* ctl, int launch, const Work& w) {
@@ -139,6 +172,13 @@ RT_FN void prim_hits(const DevScene<R>& sc, int p, int flags, V3<R> wo, V3<R> wd
       return;
     }
     case RT355_CUBE: {  // src/shape.rs:234-248, 455-466
+      // The branch `direction >= 0` is also taken by -0.0, whose quotients then come out with the signs
+      // swapped: a ray with a zero direction component misses or hits a slab it lies inside depending on the
+      // SIGN of that zero.  In the reference that sign is whatever the 4-term row sums of inverse * direction
+      // leave (the w term m[k][3] * 0.0 is +0.0 for every transformation without a negative inverse
+      // translation, which makes the sum +0.0); here the rows have three terms and the identity skips them,
+      // so the zero is made +0.0 explicitly.
+      d = V3<R>{d.x + R(0), d.y + R(0), d.z + R(0)};
       R t0x, t1x, t0y, t1y, t0z, t1z;
       if (d.x >= R(0)) { t0x = (R(-1) - o.x) / d.x; t1x = (R(1) - o.x) / d.x; } else { t1x = (R(-1) - o.x) / d.x; t0x = (R(1) - o.x) / d.x; }
       if (d.y >= R(0)) { t0y = (R(-1) - o.y) / d.y; t1y = (R(1) - o.y) / d.y; } else { t1y = (R(-1) - o.y) / d.y; t0y = (R(1) - o.y) / d.y; }
@@ -214,6 +254,9 @@ RT_FN void prim_hits(const DevScene<R>& sc, int p, int flags, V3<R> wo, V3<R> wd
 // ------------------------------------------------------------------------------------------------
 template <class R>
 RT_FN bool tri_hit(const DevTri& T, V3<R> o, V3<R> d, R& t, R& u, R& v) {
+#ifdef RT355_EXP_NO_TRI
+  return false;  // timing experiment only: what the frame costs without any triangle arithmetic
+#endif
   const V3<R> p1 = {R(T.p1[0]), R(T.p1[1]), R(T.p1[2])};
   const V3<R> e1 = {R(T.p2[0]) - p1.x, R(T.p2[1]) - p1.y, R(T.p2[2]) - p1.z};  // src/triangle.rs:83
   const V3<R> e2 = {R(T.p3[0]) - p1.x, R(T.p3[1]) - p1.y, R(T.p3[2]) - p1.z};  // src/triangle.rs:84
@@ -311,6 +354,15 @@ RT_FN void traverse(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work& wk,
   int sp = 0;
   int cur = 0;
   for (;;) {
+#ifdef RT355_EXP_STAMPS
+    DbgAcc& dacc = wk.dbg;
+    // wave-level view: a trip runs the node body when some lane is at a node, the leaf bodies when some lane is at a leaf
+    const unsigned long long dc0 = __builtin_amdgcn_s_memtime();
+    const bool d_node = __ballot(cur >= 0) != 0ull;
+    const bool d_tri = __ballot(cur < 0 && (((uint32_t)~cur) & LEAF_TRI_BIT)) != 0ull, d_prim = __ballot(cur < 0 && !(((uint32_t)~cur) & LEAF_TRI_BIT)) != 0ull;
+    dacc.trips++, dacc.n_node += d_node, dacc.n_leaf += d_tri || d_prim;
+    struct Closer { DbgAcc& a; unsigned long long c0; bool n, t, p; RT_FN ~Closer() { const unsigned long long dt = __builtin_amdgcn_s_memtime() - c0; const int k = (int)n + (int)t + (int)p; if (k) { if (n) a.cyc_node += dt / k; if (t) a.cyc_tri += dt / k; if (p) a.cyc_prim += dt / k; } } } closer{dacc, dc0, d_node, d_tri, d_prim};
+#endif
     if (cur >= 0) {
       const BvhNode4 N = sc.nodes[cur];
       float tlo, thi;
@@ -402,6 +454,13 @@ RT_FN void traverse_packet(const DevScene<R>& sc, V3<R> o, V3<R> d, bool live, V
   int cur = 0;
   for (;;) {
     if (__ballot(live) == 0ull) return;
+#ifdef RT355_EXP_STAMPS
+    DbgAcc& dacc = wk.dbg;
+    const unsigned long long dc0 = __builtin_amdgcn_s_memtime();
+    const bool d_node = cur >= 0, d_tri = cur < 0 && (((uint32_t)~cur) & LEAF_TRI_BIT), d_prim = cur < 0 && !d_tri;
+    dacc.trips++, dacc.n_node += d_node, dacc.n_leaf += !d_node;
+    struct Closer { DbgAcc& a; unsigned long long c0; bool n, t, p; RT_FN ~Closer() { const unsigned long long dt = __builtin_amdgcn_s_memtime() - c0; if (n) a.cyc_node += dt; if (t) a.cyc_tri += dt; if (p) a.cyc_prim += dt; } } closer{dacc, dc0, d_node, d_tri, d_prim};
+#endif
     if (cur >= 0) {
       cptr<float> q = (cptr<float>)(const float*)&sc.nodes[cur].box[0][0];
       cptr<int32_t> qc = (cptr<int32_t>)(const int32_t*)&sc.nodes[cur].c[0];
@@ -468,6 +527,97 @@ RT_FN void traverse_packet(const DevScene<R>& sc, V3<R> o, V3<R> d, bool live, V
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Quad traversal: FOUR adjacent lanes walk the tree for ONE ray.  At an inner node each lane fetches and
+// tests one of the four child boxes (the quad reads the node as one 128-byte line); in a leaf each lane
+// tests one of the (up to four) primitives.  The dependent instruction chain of a ray is a quarter of what
+// one lane alone would issue, which is what bounds the deeper generations: they hold about as many rays as
+// the chip has lanes, so their launches last as long as the slowest single traversal.  The stack is one LDS
+// column per quad, read by all four lanes and written by the lane that owns the child.  Lanes of a quad
+// exchange values through DPP quad permutes (no LDS, no scalar unit); every exchange sits where the four
+// lanes are converged.
+// Visitors are the same as for the other traversals; each lane keeps the result of the primitives it
+// tested itself and the visitor's quad_* member merges the four afterwards.
+// ------------------------------------------------------------------------------------------------
+constexpr int QUADS = BLOCK / 4;  // rays a block traverses at a time, and the stride of a quad's stack column
+
+template <int J> RT_FN int quad_bcast(int v) { return __builtin_amdgcn_mov_dpp(v, J * 0x55, 0xF, 0xF, true); }
+RT_FN int quad_swap1(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }  // lanes 1,0,3,2
+RT_FN int quad_swap2(int v) { return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true); }  // lanes 2,3,0,1
+RT_FN float quad_swap1(float v) { return __int_as_float(quad_swap1(__float_as_int(v))); }
+RT_FN float quad_swap2(float v) { return __int_as_float(quad_swap2(__float_as_int(v))); }
+RT_FN double quad_swap1(double v) { return __hiloint2double(quad_swap1(__double2hiint(v)), quad_swap1(__double2loint(v))); }
+RT_FN double quad_swap2(double v) { return __hiloint2double(quad_swap2(__double2hiint(v)), quad_swap2(__double2loint(v))); }
+RT_FN float quad_min(float v) {
+  v = fminf(v, quad_swap1(v));
+  return fminf(v, quad_swap2(v));
+}
+RT_FN bool quad_any(bool b) {
+  int v = b ? 1 : 0;
+  v |= quad_swap1(v);
+  v |= quad_swap2(v);
+  return v != 0;
+}
+
+template <class R, bool COUNT, class Vis>
+RT_FN void traverse_quad(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work& wk, int* stack) {
+  const int ql = threadIdx.x & 3;
+  bool stop = false;
+  for (int p = sc.n_bounded + ql; p < sc.n_prims; p += 4) stop |= vis.prim(p);
+  if (quad_any(stop) || sc.n_nodes == 0) return;
+  const SlabRay sr = make_slab_ray(o, d, sc.box_abs_max);
+  float tlo, thi;
+  slab_interval(vis.tmin(), vis.tmax(), tlo, thi);
+  thi = quad_min(thi);
+  int sp = 0;
+  int cur = 0;
+  for (;;) {
+    if (cur >= 0) {
+      const float* b = sc.nodes[cur].box[ql];
+      const float lox = b[0], loy = b[1], loz = b[2], hix = b[3], hiy = b[4], hiz = b[5];
+      const int child = sc.nodes[cur].c[ql];
+      if constexpr (COUNT) wk.box += child != -1;
+      float tn;
+      const bool h = slab_test(sr, lox, loy, loz, hix, hiy, hiz, tlo, thi, tn);
+      // Nearest first.  Keys are made distinct by the lane number in their two lowest bits, misses sort
+      // last; a lane's rank is the number of smaller keys in its quad.
+      const uint32_t MISS = 0xFFFFFFFCu;
+      const uint32_t key = (h ? (__float_as_uint(fmaxf(tn, 0.f)) & ~3u) : MISS) | (uint32_t)ql;
+      const uint32_t k0 = (uint32_t)quad_bcast<0>((int)key), k1 = (uint32_t)quad_bcast<1>((int)key);
+      const uint32_t k2 = (uint32_t)quad_bcast<2>((int)key), k3 = (uint32_t)quad_bcast<3>((int)key);
+      const int rank = (k0 < key) + (k1 < key) + (k2 < key) + (k3 < key);
+      const int nh = (k0 < MISS) + (k1 < MISS) + (k2 < MISS) + (k3 < MISS);  // the same in all four lanes
+      if (h && rank > 0) stack[(sp + nh - 1 - rank) * QUADS] = child;  // farthest lowest: the next pop is the nearest
+      int next = (h && rank == 0) ? child : 0;
+      next |= quad_swap1(next);
+      next |= quad_swap2(next);
+      if (nh > 0) {
+        sp += nh - 1;
+        cur = next;
+        continue;
+      }
+    } else {
+      const uint32_t leaf = (uint32_t)~cur;
+      const int first = (int)(leaf & LEAF_FIRST_MASK), count = (int)(leaf >> 26);
+      if (leaf & LEAF_TRI_BIT) {
+        for (int k = ql; k < count; k += 4) {
+          const DevTri T = sc.tri[first + k];
+          if constexpr (COUNT) wk.prim[T.flags & PF_KIND_MASK]++;
+          stop |= vis.tri(first + k, T);
+        }
+      } else {
+        for (int k = ql; k < count; k += 4) stop |= vis.prim(first + k);
+      }
+      if (quad_any(stop)) return;
+      slab_interval(vis.tmin(), vis.tmax(), tlo, thi);
+      thi = quad_min(thi);
+    }
+    if (sp == 0) return;
+    --sp;
+    cur = stack[sp * QUADS];
+  }
+}
+
 // Nearest hit with t >= 0; among equal t the lowest shape index wins (stable sort src/world.rs:42 +
 // first minimum src/intersection.rs:151).  NaN t never qualifies.
 template <class R, bool COUNT>
@@ -493,6 +643,25 @@ struct ClosestVis {
     R t, u, v;
     if (tri_hit(T, o, d, t, u, v)) accept(t, u, v, p, T.shape, T.flags);
     return false;
+  }
+  // After a quad traversal: true in the ONE lane of the quad whose own result is the quad's nearest hit by
+  // the same order as accept() (t, then shape index; the lane number settles what is left, which is only
+  // the case of four misses).  That lane writes the ray's record.
+  RT_FN bool quad_winner() const {
+    const int ql = threadIdx.x & 3;
+    R t = best_t;
+    int s = best_s, l = ql;
+    {
+      const R tp = quad_swap1(t);
+      const int sp = quad_swap1(s), lp = quad_swap1(l);
+      if (tp < t || (tp == t && (sp < s || (sp == s && lp < l)))) t = tp, s = sp, l = lp;
+    }
+    {
+      const R tp = quad_swap2(t);
+      const int sp = quad_swap2(s), lp = quad_swap2(l);
+      if (tp < t || (tp == t && (sp < s || (sp == s && lp < l)))) t = tp, s = sp, l = lp;
+    }
+    return l == ql;
   }
 };
 
@@ -633,11 +802,69 @@ RT_FN void primary_ray(const DevCamera<R>& cam, uint32_t i, V3<R>& org, V3<R>& d
 template <class R, bool COUNT, bool PACKET>
 RT_FN void shade_surface(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t r, bool valid, int p, int* lds, Work& wk);
 
+// One chunk of BLOCK rays of generation `gen`: World::intersect + hit() for the ray of every lane, records to
+// the pool.  With `primary` set (generation 0 of a frame) the rays come from the camera instead of the pool.
 // LAST: this is the deepest generation.  Its rays spawn nothing and nothing waits for their hit records
-// except their own shading, so the kernel goes on to shade each hit (shadow ray + lighting) and leaves the
+// except their own shading, so the chunk goes on to shade each hit (shadow ray + lighting) and leaves the
 // ray's final colour in pool.color: one launch, and one slowest-wave tail, instead of three.
+// wh / wc: this wave's hits and the upper bound of the child rays they spawn.
 template <class R, bool COUNT, bool PACKET, bool LAST>
-__global__ void __launch_bounds__(256, (PACKET && !LAST) ? 4 : 3) k_trace(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch, DevCamera<R> cam, int primary) {
+RT_FN void trace_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* ctl, const DevCamera<R>& cam, int primary, uint32_t start, uint32_t count,
+                       uint32_t base, int remaining, int launch, int* lds, Work& wk, uint32_t& wh, uint32_t& wc) {
+  const uint32_t i = base + threadIdx.x;
+  const bool valid = i < count;
+  const uint32_t r = start + (valid ? i : 0u);
+  V3<R> o, d;
+  if (primary) {  // generation 0 of a frame: the rays are made here and kept for the later kernels
+    primary_ray(cam, r, o, d);
+    if (valid) st3(pool.org + 3ull * r, o), st3(pool.dir + 3ull * r, d);
+  } else {
+    o = ld3(pool.org + 3ull * r), d = ld3(pool.dir + 3ull * r);
+  }
+  ClosestVis<R, COUNT> vis(sc, o, d, wk);
+  const bool live = valid && !(d.x == R(0) && d.y == R(0) && d.z == R(0));
+  long long t_start = 0;
+  if constexpr (COUNT) t_start = clock64();
+#ifdef RT355_EXP_STAMPS
+  const unsigned long long dbg_t0 = wall_clock64(), dbg_c0 = __builtin_amdgcn_s_memtime();
+  wk.dbg = DbgAcc{};
+#endif
+  if constexpr (PACKET) {
+    traverse_packet<R, COUNT>(sc, o, d, live, vis, wk, lds);
+  } else {
+    if (live) traverse<R, COUNT>(sc, o, d, vis, wk, lds);
+  }
+#ifdef RT355_EXP_STAMPS
+  dbg_record(launch, dbg_t0, dbg_c0, wk.dbg, live);
+#endif
+  if constexpr (COUNT) {
+    // longest traversal of one wave, in shader clocks (all lanes reconverge here)
+    const unsigned long long dt = (unsigned long long)(clock64() - t_start);
+    if ((threadIdx.x & 63u) == 0 && launch < RT355_MAX_LAUNCH) atomicMax(&ctl->work[launch][11], dt);
+  }
+  uint32_t n_child = 0;
+  const bool hit = valid && vis.best_p >= 0;
+  if (valid) {
+    pool.hit_prim[r] = vis.best_p;
+    if (hit) {
+      pool.hit_t[r] = vis.best_t;
+      pool.hit_uv[2ull * r] = vis.best_u;
+      pool.hit_uv[2ull * r + 1] = vis.best_v;
+      if (remaining > 0) n_child = ((vis.best_flags & PF_REFLECTIVE) ? 1u : 0u) + ((vis.best_flags & PF_TRANSPARENT) ? 1u : 0u);
+    }
+  }
+  if constexpr (LAST) {
+    if (__ballot(hit) != 0ull) shade_surface<R, COUNT, PACKET>(sc, pool, r, hit, hit ? vis.best_p : 0, lds, wk);
+    if (valid && !hit) st3(pool.color + 3ull * r, V3<R>{R(0), R(0), R(0)});  // src/world.rs:61-63: a miss is black
+  }
+  wh = __popcll(__ballot(hit)), wc = wave_sum(n_child);
+}
+
+// k_trace: trace_chunk over generation `gen`, one chunk per block and trip.  Leaves, per chunk, the hit count
+// and the child bound for k_scan; with `count_hits` set it adds the hits to the generation's total itself
+// (no k_scan launch follows: the frame runs the fused kernels and this is its deepest generation).
+template <class R, bool COUNT, bool PACKET, bool LAST>
+__global__ void __launch_bounds__(256, (PACKET && !LAST) ? 4 : 3) k_trace(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch, DevCamera<R> cam, int primary, int count_hits) {
   __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
   int* lds = PACKET ? lds_stack + (threadIdx.x >> 6) * STACK_DEPTH : lds_stack + threadIdx.x;
   uint32_t start, count;
@@ -647,47 +874,70 @@ __global__ void __launch_bounds__(256, (PACKET && !LAST) ? 4 : 3) k_trace(DevSce
   // one ray per lane per trip; the trip count is block-uniform, so all 64 lanes stay converged for the
   // ballots of the packet traversal
   for (uint32_t base = blockIdx.x * BLOCK; base < count; base += gridDim.x * BLOCK) {
-    const uint32_t i = base + threadIdx.x;
-    const bool valid = i < count;
-    const uint32_t r = start + (valid ? i : 0u);
-    V3<R> o, d;
-    if (primary) {  // generation 0 of a frame: the rays are made here and kept for the later kernels
-      primary_ray(cam, r, o, d);
-      if (valid) st3(pool.org + 3ull * r, o), st3(pool.dir + 3ull * r, d);
-    } else {
-      o = ld3(pool.org + 3ull * r), d = ld3(pool.dir + 3ull * r);
-    }
-    ClosestVis<R, COUNT> vis(sc, o, d, wk);
-    const bool live = valid && !(d.x == R(0) && d.y == R(0) && d.z == R(0));
-    long long t_start = 0;
-    if constexpr (COUNT) t_start = clock64();
-    if constexpr (PACKET) {
-      traverse_packet<R, COUNT>(sc, o, d, live, vis, wk, lds);
-    } else {
-      if (live) traverse<R, COUNT>(sc, o, d, vis, wk, lds);
-    }
-    if constexpr (COUNT) {
-      // longest traversal of one wave, in shader clocks (all lanes reconverge here)
-      const unsigned long long dt = (unsigned long long)(clock64() - t_start);
-      if ((threadIdx.x & 63u) == 0 && launch < RT355_MAX_LAUNCH) atomicMax(&ctl->work[launch][11], dt);
-    }
-    uint32_t n_child = 0;
-    const bool hit = valid && vis.best_p >= 0;
-    if (valid) {
-      pool.hit_prim[r] = vis.best_p;
-      if (hit) {
-        pool.hit_t[r] = vis.best_t;
-        pool.hit_uv[2ull * r] = vis.best_u;
-        pool.hit_uv[2ull * r + 1] = vis.best_v;
-        if (remaining > 0) n_child = ((vis.best_flags & PF_REFLECTIVE) ? 1u : 0u) + ((vis.best_flags & PF_TRANSPARENT) ? 1u : 0u);
+    uint32_t wh, wc;
+    trace_chunk<R, COUNT, PACKET, LAST>(sc, pool, ctl, cam, primary, start, count, base, remaining, launch, lds, wk, wh, wc);
+    if ((threadIdx.x & 63u) == 0) s_red[threadIdx.x >> 6] = wh, s_red[BLOCK / 64 + (threadIdx.x >> 6)] = wc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t th = 0, tc = 0;
+      for (int w = 0; w < BLOCK / 64; ++w) th += s_red[w], tc += s_red[BLOCK / 64 + w];
+      if (count_hits) {
+        if (th) atomicAdd(&ctl->hit_count[gen].v, th);
+      } else {
+        pool.blk_hits[base / BLOCK] = th;
+        pool.blk_children[base / BLOCK] = tc;
       }
     }
-    if constexpr (LAST) {
-      if (__ballot(hit) != 0ull) shade_surface<R, COUNT, PACKET>(sc, pool, r, hit, hit ? vis.best_p : 0, lds, wk);
-      if (valid && !hit) st3(pool.color + 3ull * r, V3<R>{R(0), R(0), R(0)});  // src/world.rs:61-63: a miss is black
+    __syncthreads();
+  }
+  flush_work<COUNT>(ctl, launch, wk);
+}
+
+// k_trace with the quad traversal: a block of 256 threads takes 256 rays per trip, 64 at a time, four lanes
+// to a ray.  Same outputs as k_trace (hit records, per-256-ray hit and child counts for k_scan).
+template <class R, bool COUNT>
+__global__ void __launch_bounds__(256, 4) k_trace_q(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch, DevCamera<R> cam, int primary) {
+  __shared__ int lds_stack[QUADS * STACK_DEPTH];
+  int* stack = lds_stack + (threadIdx.x >> 2);
+  __shared__ uint32_t s_red[2 * (BLOCK / 64)];
+  uint32_t start, count;
+  gen_range(ctl, gen, pool.capacity, start, count);
+  Work wk;
+  for (uint32_t base = blockIdx.x * BLOCK; base < count; base += gridDim.x * BLOCK) {
+    uint32_t wh = 0, wc = 0;  // this wave's hits and child-ray bound over the four passes
+    for (int sub = 0; sub < 4; ++sub) {
+      const uint32_t i = base + sub * QUADS + (threadIdx.x >> 2);
+      const bool valid = i < count;
+      const uint32_t r = start + (valid ? i : 0u);
+      const bool writer = (threadIdx.x & 3u) == 0;
+      V3<R> o, d;
+      if (primary) {
+        primary_ray(cam, r, o, d);
+        if (valid && writer) st3(pool.org + 3ull * r, o), st3(pool.dir + 3ull * r, d);
+      } else {
+        o = ld3(pool.org + 3ull * r), d = ld3(pool.dir + 3ull * r);
+      }
+      ClosestVis<R, COUNT> vis(sc, o, d, wk);
+      const bool live = valid && !(d.x == R(0) && d.y == R(0) && d.z == R(0));  // the same in the four lanes of a quad
+      if (live) traverse_quad<R, COUNT>(sc, o, d, vis, wk, stack);
+      const bool mine = vis.quad_winner() && valid;  // one lane per ray
+      const bool hit = mine && vis.best_p >= 0;
+      if (mine) {
+        pool.hit_prim[r] = vis.best_p;
+        if (hit) {
+          pool.hit_t[r] = vis.best_t;
+          pool.hit_uv[2ull * r] = vis.best_u;
+          pool.hit_uv[2ull * r + 1] = vis.best_v;
+        } else if (remaining == 0) {
+          // deepest generation: no combine launch of its own will visit this ray, its parent reads the colour
+          // as it is (src/world.rs:61-63: a miss is black)
+          st3(pool.color + 3ull * r, V3<R>{R(0), R(0), R(0)});
+        }
+      }
+      const bool spawns = hit && remaining > 0;
+      wh += __popcll(__ballot(hit));
+      wc += __popcll(__ballot(spawns && (vis.best_flags & PF_REFLECTIVE))) + __popcll(__ballot(spawns && (vis.best_flags & PF_TRANSPARENT)));
     }
-    // per block of rays: hits (= shadow rays) and the upper bound of child rays, for k_scan
-    const uint32_t wh = __popcll(__ballot(hit)), wc = wave_sum(n_child);
     if ((threadIdx.x & 63u) == 0) s_red[threadIdx.x >> 6] = wh, s_red[BLOCK / 64 + (threadIdx.x >> 6)] = wc;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -894,6 +1144,7 @@ RT_FN void shade_surface(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t
   } else {
     if (valid) traverse<R, COUNT>(sc, pc.over_point, ldir, av, wk, lds);
   }
+
   if (valid) {
     const DevMaterial<R>& m = sc.materials[info.flags >> PF_MAT_SHIFT];
     st3(pool.color + 3ull * r, lighting(sc, m, pc.over_point, pc.eyev, pc.normalv, av.found));
@@ -951,10 +1202,9 @@ RT_FN void container_indices(const DevScene<R>& sc, bool need, int p, PrimInfo i
   const bool others_unit = (info.flags & PF_OTHERS_UNIT) != 0;
   const R floor_t = (others_unit && h_before) ? hmt : -inf<R>();
   const int floor_s = (others_unit && h_before) ? info.shape : -1;
-  // Reversed ray.  A zero component keeps its sign: the cube's slab test branches on d >= 0
-  // (src/shape.rs:455-466), which -0.0 passes, so flipping the sign of a zero would turn a slab the forward
-  // ray lies inside into a miss, and the reversed ray would no longer see the forward ray's intersections.
-  const V3<R> rd = {d.x == R(0) ? d.x : -d.x, d.y == R(0) ? d.y : -d.y, d.z == R(0) ? d.z : -d.z};
+  // Reversed ray: 0 - d, so that a zero component stays +0.0 (negation would make it -0.0, and the cube's
+  // slab test, which branches on d >= 0 (src/shape.rs:455-466), tells the two apart).
+  const V3<R> rd = {R(0) - d.x, R(0) - d.y, R(0) - d.z};
   bool searching = need && !(others_unit && !h_before), found = false;
   int other_flags = 0, other_s = -1;
   R other_t = R(0);
@@ -1018,12 +1268,177 @@ __global__ void __launch_bounds__(256, PACKET ? 4 : 3) k_shadow(DevScene<R> sc, 
   flush_work<COUNT>(ctl, launch, wk);
 }
 
+// k_shadow with the quad traversal.  Per trip a wave takes 64 rays: (1) one lane per ray prepares the shadow
+// ray of its hit and leaves it in LDS, the lanes with a hit are listed compactly; (2) the wave walks that list
+// 16 shadow rays at a time, four lanes to a ray; (3) one lane per ray again: lighting with the flag found.
+// Everything a wave exchanges through LDS is its own (no block barrier); LDS operations of one wave execute
+// in order, the fences only keep the compiler from moving them.
+template <class R, bool COUNT>
+__global__ void __launch_bounds__(256, 4) k_shadow_q(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int launch) {
+  uint32_t start, gcount;
+  gen_range(ctl, gen, pool.capacity, start, gcount);
+  __shared__ int lds_stack[QUADS * STACK_DEPTH];
+  __shared__ R s_ray[BLOCK * 7];  // over_point, direction to the light, distance + EPSILON
+  __shared__ uint8_t s_list[BLOCK], s_found[BLOCK];
+  int* stack = lds_stack + (threadIdx.x >> 2);
+  const uint32_t lane = threadIdx.x & 63u, wbase = threadIdx.x & ~63u;
+  Work wk;
+  for (uint32_t rbase = blockIdx.x * BLOCK; rbase < gcount; rbase += gridDim.x * BLOCK) {
+    const uint32_t i = rbase + threadIdx.x;
+    const uint32_t r = start + (i < gcount ? i : 0u);
+    const int p_raw = pool.hit_prim[r];
+    const bool valid = i < gcount && p_raw >= 0;
+    const unsigned long long m = __ballot(valid);
+    if (m == 0ull) continue;  // wave-uniform
+    const int p = valid ? p_raw : 0;
+    const PrimInfo info = sc.prim_info[p];
+    Prepared<R> pc;
+    pc.over_point = {R(0), R(0), R(0)};
+    if (valid) {
+      pc = prepare(sc, pool, r, p, info.flags);
+      const V3<R> lv = ld3(sc.light_pos) - pc.over_point;  // src/world.rs:46-49
+      const R distance = sqrt(dot(lv, lv));
+      R* q = s_ray + (size_t)threadIdx.x * 7;
+      st3(q, pc.over_point);
+      st3(q + 3, V3<R>{lv.x / distance, lv.y / distance, lv.z / distance});
+      q[6] = distance + eps<R>();
+      s_list[wbase + __popcll(m & lanes_below())] = (uint8_t)lane;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t n_valid = __popcll(m);
+    for (uint32_t sb = 0; sb * 16u < n_valid; ++sb) {
+      const uint32_t slot = sb * 16u + (lane >> 2);
+      if (slot < n_valid) {  // the same in the four lanes of a quad
+        const uint32_t src = s_list[wbase + slot];
+        const R* q = s_ray + (size_t)(wbase + src) * 7;
+        const V3<R> so = ld3(q), sd = ld3(q + 3);
+        AnyVis<R, COUNT> av(sc, so, sd, q[6], wk);
+        traverse_quad<R, COUNT>(sc, so, sd, av, wk, stack);
+        const bool found = quad_any(av.found);
+        if ((lane & 3u) == 0) s_found[wbase + src] = found ? 1 : 0;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (valid) {
+      const DevMaterial<R>& mat = sc.materials[info.flags >> PF_MAT_SHIFT];
+      st3(pool.color + 3ull * r, lighting(sc, mat, pc.over_point, pc.eyev, pc.normalv, s_found[threadIdx.x] != 0));
+    }
+  }
+  flush_work<COUNT>(ctl, launch, wk);
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_spawn: the reflected / refracted rays of every hit of generation `gen` (src/world.rs:68-102) and the
 // Schlick reflectance (src/computation.rs:20-33), with n1 / n2 looked up first for hits on transparent
 // shapes.  Launched while rays may still be spawned (remaining > 0); the deepest generation has no
 // children and k_combine is told so.
 // ------------------------------------------------------------------------------------------------
+// One chunk of BLOCK rays: the child rays of its hits are placed from `base` (an offset into generation
+// gen + 1) on, reflected before refracted inside each wave, waves in order.  Called by every thread of the
+// block (it synchronises the block).
+template <class R, bool COUNT, bool PACKET>
+RT_FN void spawn_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* ctl, int gen, uint32_t start, uint32_t gcount, uint32_t rbase, uint32_t base,
+                       int any_transparent, int* lds, uint32_t* s_cnt, Work& wk) {
+  const uint32_t child_start = start + gcount;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t i = rbase + threadIdx.x;
+  const uint32_t r = start + (i < gcount ? i : 0u);
+  const int p_raw = pool.hit_prim[r];
+  const bool valid = i < gcount && p_raw >= 0;
+  if (__syncthreads_or(valid) == 0) return;  // block-uniform
+  const int p = valid ? p_raw : 0;
+  const PrimInfo info = sc.prim_info[p];
+  const bool slot_r = valid && (info.flags & PF_REFLECTIVE);
+  const bool slot_t = valid && (info.flags & PF_TRANSPARENT);
+  R n1 = R(1), n2 = R(1);
+  if (any_transparent && __ballot(slot_t) != 0ull) {  // wave-uniform
+    const V3<R> o = ld3(pool.org + 3ull * r), d = ld3(pool.dir + 3ull * r);
+    container_indices<R, COUNT, PACKET>(sc, slot_t, p, info, o, d, pool.hit_t[r], lds, wk, n1, n2);
+  }
+  bool want_refr = false;
+  V3<R> refl_o = {R(0), R(0), R(0)}, refl_d = refl_o, refr_o = refl_o, refr_d = refl_o;
+  R rs = R(-1);
+  if (slot_r || slot_t) {
+    const Prepared<R> c = prepare(sc, pool, r, p, info.flags);
+    refl_o = c.over_point;
+    refl_d = reflect(c.d, c.normalv_temp);  // un-flipped normal (src/intersection.rs:85)
+    if (slot_t) {
+      const R n_ratio = n1 / n2;
+      const R cos_ti = dot(c.eyev, c.normalv);
+      const R sin2_t = n_ratio * n_ratio * (R(1) - cos_ti * cos_ti);
+      if (!(sin2_t > R(1))) {
+        const R cos_t = sqrt(R(1) - sin2_t);
+        refr_o = c.under_point;
+        refr_d = (n_ratio * cos_ti - cos_t) * c.normalv - n_ratio * c.eyev;
+        want_refr = true;
+      }
+      if (info.flags & PF_SCHLICK) {  // reflective > 0 && transparency > 0 (src/world.rs:120): schlick()
+        R cs = cos_ti;
+        bool tir = false;
+        if (n1 > n2) {
+          const R n = n1 / n2;
+          const R s2 = n * n * (R(1) - cs * cs);
+          if (s2 > R(1)) tir = true;
+          else cs = sqrt(R(1) - s2);
+        }
+        if (tir) {
+          rs = R(1);
+        } else {
+          R r0 = (n1 - n2) / (n1 + n2);
+          r0 = r0 * r0;
+          const R k = R(1) - cs;
+          rs = r0 + ((R(1) - r0) * (k * k * k * k * k));
+        }
+      }
+    }
+  }
+
+  // child ids: the chunk's base + rank inside the chunk; the bound counts a refracted ray for every
+  // transparent hit, so a hit that turns out to be total internal reflection leaves its slot empty (zero
+  // direction = no ray).
+  const unsigned long long m_r = __ballot(slot_r), m_t = __ballot(slot_t);
+  const uint32_t n_r = __popcll(m_r);
+  if ((threadIdx.x & 63u) == 0) s_cnt[wave] = n_r + __popcll(m_t);
+  __syncthreads();
+  for (int w = 0; w < BLOCK / 64; ++w)
+    if (w < (int)wave) base += s_cnt[w];
+  const uint32_t off_r = __popcll(m_r & lanes_below()), off_t = n_r + __popcll(m_t & lanes_below());
+  __syncthreads();
+  const uint32_t n_holes = __popcll(__ballot(slot_t && !want_refr));
+  if ((threadIdx.x & 63u) == 0 && n_holes) atomicAdd(&ctl->holes[gen + 1].v, n_holes);
+
+  int32_t child_r = -1, child_t = -1;
+  if (slot_r) {
+    const unsigned long long id = (unsigned long long)child_start + base + off_r;
+    if (id < (unsigned long long)pool.capacity) {
+      child_r = (int32_t)id;
+      st3(pool.org + 3ull * id, refl_o);
+      st3(pool.dir + 3ull * id, refl_d);
+    } else {
+      ctl->overflow.v = 1;
+    }
+  }
+  if (slot_t) {
+    const unsigned long long id = (unsigned long long)child_start + base + off_t;
+    if (id < (unsigned long long)pool.capacity) {
+      if (want_refr) child_t = (int32_t)id;
+      st3(pool.org + 3ull * id, refr_o);
+      st3(pool.dir + 3ull * id, refr_d);  // zero when there is no refracted ray
+    } else {
+      ctl->overflow.v = 1;
+    }
+  }
+  if (slot_r || slot_t) {  // k_combine looks at these only for hits on reflective / transparent shapes
+    pool.child[2ull * r] = child_r;
+    pool.child[2ull * r + 1] = child_t;
+    pool.mixr[r] = rs;
+  }
+}
+
 template <class R, bool COUNT, bool PACKET>
 __global__ void __launch_bounds__(256, 3) k_spawn(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int any_transparent, int launch) {
   __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
@@ -1031,104 +1446,68 @@ __global__ void __launch_bounds__(256, 3) k_spawn(DevScene<R> sc, RayPool<R> poo
   Work wk;
   uint32_t start, gcount;
   gen_range(ctl, gen, pool.capacity, start, gcount);
-  const uint32_t child_start = start + gcount;
-  const uint32_t wave = threadIdx.x >> 6;
   __shared__ uint32_t s_cnt[BLOCK / 64];
   // block-uniform trip count: every wave reaches the barriers
-  for (uint32_t rbase = blockIdx.x * BLOCK; rbase < gcount; rbase += gridDim.x * BLOCK) {
-    const uint32_t i = rbase + threadIdx.x;
-    const uint32_t r = start + (i < gcount ? i : 0u);
-    const int p_raw = pool.hit_prim[r];
-    const bool valid = i < gcount && p_raw >= 0;
-    if (__syncthreads_or(valid) == 0) continue;  // block-uniform
-    const int p = valid ? p_raw : 0;
-    const PrimInfo info = sc.prim_info[p];
-    const bool slot_r = valid && (info.flags & PF_REFLECTIVE);
-    const bool slot_t = valid && (info.flags & PF_TRANSPARENT);
-    R n1 = R(1), n2 = R(1);
-    if (any_transparent && __ballot(slot_t) != 0ull) {  // wave-uniform
-      const V3<R> o = ld3(pool.org + 3ull * r), d = ld3(pool.dir + 3ull * r);
-      container_indices<R, COUNT, PACKET>(sc, slot_t, p, info, o, d, pool.hit_t[r], lds, wk, n1, n2);
-    }
-    bool want_refr = false;
-    V3<R> refl_o = {R(0), R(0), R(0)}, refl_d = refl_o, refr_o = refl_o, refr_d = refl_o;
-    R rs = R(-1);
-    if (slot_r || slot_t) {
-      const Prepared<R> c = prepare(sc, pool, r, p, info.flags);
-      refl_o = c.over_point;
-      refl_d = reflect(c.d, c.normalv_temp);  // un-flipped normal (src/intersection.rs:85)
-      if (slot_t) {
-        const R n_ratio = n1 / n2;
-        const R cos_ti = dot(c.eyev, c.normalv);
-        const R sin2_t = n_ratio * n_ratio * (R(1) - cos_ti * cos_ti);
-        if (!(sin2_t > R(1))) {
-          const R cos_t = sqrt(R(1) - sin2_t);
-          refr_o = c.under_point;
-          refr_d = (n_ratio * cos_ti - cos_t) * c.normalv - n_ratio * c.eyev;
-          want_refr = true;
-        }
-        if (info.flags & PF_SCHLICK) {  // reflective > 0 && transparency > 0 (src/world.rs:120): schlick()
-          R cs = cos_ti;
-          bool tir = false;
-          if (n1 > n2) {
-            const R n = n1 / n2;
-            const R s2 = n * n * (R(1) - cs * cs);
-            if (s2 > R(1)) tir = true;
-            else cs = sqrt(R(1) - s2);
-          }
-          if (tir) {
-            rs = R(1);
-          } else {
-            R r0 = (n1 - n2) / (n1 + n2);
-            r0 = r0 * r0;
-            const R k = R(1) - cs;
-            rs = r0 + ((R(1) - r0) * (k * k * k * k * k));
-          }
-        }
-      }
-    }
+  for (uint32_t rbase = blockIdx.x * BLOCK; rbase < gcount; rbase += gridDim.x * BLOCK)
+    spawn_chunk<R, COUNT, PACKET>(sc, pool, ctl, gen, start, gcount, rbase, pool.blk_base[rbase / BLOCK], any_transparent, lds, s_cnt, wk);
+  flush_work<COUNT>(ctl, launch, wk);
+}
 
-    // child ids: this block's prefix from k_scan + rank inside the block; the bound counts a refracted
-    // ray for every transparent hit, so a hit that turns out to be total internal reflection leaves
-    // its slot empty (zero direction = no ray).
-    const unsigned long long m_r = __ballot(slot_r), m_t = __ballot(slot_t);
-    const uint32_t n_r = __popcll(m_r);
-    if ((threadIdx.x & 63u) == 0) s_cnt[wave] = n_r + __popcll(m_t);
-    __syncthreads();
-    uint32_t base = pool.blk_base[rbase / BLOCK];
-    for (int w = 0; w < BLOCK / 64; ++w)
-      if (w < (int)wave) base += s_cnt[w];
-    const uint32_t off_r = __popcll(m_r & lanes_below()), off_t = n_r + __popcll(m_t & lanes_below());
-    __syncthreads();
-    const uint32_t n_holes = __popcll(__ballot(slot_t && !want_refr));
-    if ((threadIdx.x & 63u) == 0 && n_holes) atomicAdd(&ctl->holes[gen + 1].v, n_holes);
+// ------------------------------------------------------------------------------------------------
+// k_trace_spawn: k_trace, k_scan and k_spawn of one generation in ONE launch.  A block traces its chunks,
+// takes the slots of all their child rays with a single atomic on the next generation's size (one word takes
+// fewer than 100 atomics per microsecond, so a block of a large generation takes several chunks per atomic),
+// then writes the children.  The order in which blocks get their slots varies from run to run; nothing
+// depends on it, a ray's colour is a function of the ray alone.  Saves two dependent launches per generation.
+// ------------------------------------------------------------------------------------------------
+constexpr int MAX_CPB = 4;  // chunks a block takes per trip at most
 
-    int32_t child_r = -1, child_t = -1;
-    if (slot_r) {
-      const unsigned long long id = (unsigned long long)child_start + base + off_r;
-      if (id < (unsigned long long)pool.capacity) {
-        child_r = (int32_t)id;
-        st3(pool.org + 3ull * id, refl_o);
-        st3(pool.dir + 3ull * id, refl_d);
-      } else {
-        ctl->overflow.v = 1;
+template <class R, bool COUNT, bool PACKET>
+__global__ void __launch_bounds__(256, 3) k_trace_spawn(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch, DevCamera<R> cam, int primary, int any_transparent) {
+  __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
+  int* lds = PACKET ? lds_stack + (threadIdx.x >> 6) * STACK_DEPTH : lds_stack + threadIdx.x;
+  __shared__ uint32_t s_red[2 * (BLOCK / 64)], s_cnt[BLOCK / 64], s_chunk[MAX_CPB], s_base;
+  uint32_t start, count;
+  gen_range(ctl, gen, pool.capacity, start, count);
+  const uint32_t nchunks = (count + BLOCK - 1) / BLOCK;
+  uint32_t cpb = (nchunks + gridDim.x - 1) / gridDim.x;
+  cpb = cpb < 1u ? 1u : (cpb > (uint32_t)MAX_CPB ? (uint32_t)MAX_CPB : cpb);
+  const uint32_t trips = (nchunks + cpb - 1) / cpb;
+  Work wk;
+  // A trip takes the chunks trip, trip + trips, ...: neighbouring chunks cost alike (they are neighbouring
+  // image regions), so the expensive ones spread over the blocks.  Trip and chunk counts are block-uniform.
+  for (uint32_t trip = blockIdx.x; trip < trips; trip += gridDim.x) {
+    uint32_t hits = 0;  // thread 0 only
+    for (uint32_t c = 0; c < cpb; ++c) {
+      const uint32_t chunk = trip + c * trips;
+      if (threadIdx.x == 0) s_chunk[c] = 0;
+      if (chunk >= nchunks) continue;
+      uint32_t wh, wc;
+      trace_chunk<R, COUNT, PACKET, false>(sc, pool, ctl, cam, primary, start, count, chunk * BLOCK, remaining, launch, lds, wk, wh, wc);
+      if ((threadIdx.x & 63u) == 0) s_red[threadIdx.x >> 6] = wh, s_red[BLOCK / 64 + (threadIdx.x >> 6)] = wc;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        uint32_t tc = 0;
+        for (int w = 0; w < BLOCK / 64; ++w) hits += s_red[w], tc += s_red[BLOCK / 64 + w];
+        s_chunk[c] = tc;
       }
+      __syncthreads();
     }
-    if (slot_t) {
-      const unsigned long long id = (unsigned long long)child_start + base + off_t;
-      if (id < (unsigned long long)pool.capacity) {
-        if (want_refr) child_t = (int32_t)id;
-        st3(pool.org + 3ull * id, refr_o);
-        st3(pool.dir + 3ull * id, refr_d);  // zero when there is no refracted ray
-      } else {
-        ctl->overflow.v = 1;
-      }
+    if (threadIdx.x == 0) {
+      uint32_t total = 0;
+      for (uint32_t c = 0; c < cpb; ++c) total += s_chunk[c];
+      s_base = total ? atomicAdd(&ctl->gen_count[gen + 1].v, total) : 0u;
+      if (hits) atomicAdd(&ctl->hit_count[gen].v, hits);
     }
-    if (slot_r || slot_t) {  // k_combine looks at these only for hits on reflective / transparent shapes
-      pool.child[2ull * r] = child_r;
-      pool.child[2ull * r + 1] = child_t;
-      pool.mixr[r] = rs;
+    __syncthreads();
+    uint32_t base = s_base;
+    for (uint32_t c = 0; c < cpb; ++c) {
+      const uint32_t n = s_chunk[c];  // block-uniform
+      if (n == 0) continue;
+      spawn_chunk<R, COUNT, PACKET>(sc, pool, ctl, gen, start, count, (trip + c * trips) * BLOCK, base, any_transparent, lds, s_cnt, wk);
+      base += n;
     }
+    __syncthreads();
   }
   flush_work<COUNT>(ctl, launch, wk);
 }
@@ -1228,6 +1607,23 @@ __global__ void __launch_bounds__(256) k_shadow_points(DevScene<R> sc, const flo
   AnyVis<R, false> av(sc, p, ldir, distance + eps<R>(), wk);
   traverse<R, false>(sc, p, ldir, av, wk, lds_stack + threadIdx.x);
   out[i] = av.found ? 1 : 0;
+}
+
+// the same with the quad traversal: four lanes to a point
+template <class R>
+__global__ void __launch_bounds__(256) k_shadow_points_q(DevScene<R> sc, const float* pts, uint32_t n, uint8_t* out) {
+  __shared__ int lds_stack[QUADS * STACK_DEPTH];
+  const uint32_t i = blockIdx.x * QUADS + (threadIdx.x >> 2);
+  if (i >= n) return;  // whole quads leave together
+  Work wk;
+  const V3<R> p = {R(pts[3 * i]), R(pts[3 * i + 1]), R(pts[3 * i + 2])};
+  const V3<R> lv = ld3(sc.light_pos) - p;
+  const R distance = sqrt(dot(lv, lv));
+  const V3<R> ldir = {lv.x / distance, lv.y / distance, lv.z / distance};
+  AnyVis<R, false> av(sc, p, ldir, distance + eps<R>(), wk);
+  traverse_quad<R, false>(sc, p, ldir, av, wk, lds_stack + (threadIdx.x >> 2));
+  const bool found = quad_any(av.found);
+  if ((threadIdx.x & 3u) == 0) out[i] = found ? 1 : 0;
 }
 
 // caller-supplied rays (n*6 floats) -> pool generation 0

@@ -75,6 +75,9 @@ struct rt355_ctx {
   int packet_gens = 1;  // generations 0..packet_gens-1 use the wave-packet traversal (primary rays and their shadow rays)
   int combine_levels = 2;  // generations folded into the first combine launch by walking ray subtrees (0..3)
   int shadow_lag = 0;   // the shadow launch of generation g is released behind the spawn of generation g + lag
+  int quad = 0;         // generations beyond packet_gens, four lanes to a ray instead of one: bit 0 k_trace_q, bit 1 k_shadow_q
+  int fused = 0;        // k_trace_spawn: trace + slot allocation + spawn of a generation in one launch (0: k_trace, k_scan, k_spawn)
+  uint32_t fused_grid = 4096;  // blocks of a k_trace_spawn launch at most; larger generations take several chunks per block
   DevBuf org, dir, hit_t, hit_uv, hit_prim, color, mixr, child, blk_hits, blk_children, blk_base, ctl, io_in, io_out, io_out2;
   hipEvent_t ev[RT355_MAX_LAUNCH + 1] = {};  // timing mode: one before every launch, one behind the last
   FrameCtl* ctl_host = nullptr;  // pinned
@@ -194,7 +197,9 @@ int ensure_pool(rt355_ctx* c, uint64_t n_primary, bool secondary, RayPool<R>& po
 
 struct LaunchLog {
   int n = 0;
-  int depth = 0;  // deepest generation: its trace launch also shades
+  int depth = 0;  // deepest generation
+  bool fused = false;      // k_trace_spawn launches: a trace launch also allocates and writes the child rays
+  bool fused_last = true;  // its trace launch also shades (k_trace<..., LAST>); false: a shadow launch of its own
   int kind[RT355_MAX_LAUNCH], gen[RT355_MAX_LAUNCH];
 };
 
@@ -225,30 +230,49 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, uint32
     int rc;
     if ((rc = rec(RT355_K_TRACE, g))) return rc;
     const bool packet = g < c->packet_gens;
+    const bool quad = !packet && (c->quad & 1);
     const bool last = g == depth;
-    if (packet && last)
-      hipLaunchKernelGGL((k_trace<R, COUNT, true, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, 0, log.n, cam, (g == 0 && primary) ? 1 : 0);
-    else if (packet)
-      hipLaunchKernelGGL((k_trace<R, COUNT, true, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n, cam, (g == 0 && primary) ? 1 : 0);
-    else if (last)
-      hipLaunchKernelGGL((k_trace<R, COUNT, false, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, 0, log.n, cam, (g == 0 && primary) ? 1 : 0);
-    else
-      hipLaunchKernelGGL((k_trace<R, COUNT, false, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n, cam, (g == 0 && primary) ? 1 : 0);
-    log.n++;
-    if ((rc = rec(RT355_K_SCAN, g))) return rc;
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, pool.blk_hits, pool.blk_children, pool.blk_base, ctl, g, (long long)pool.capacity);
-    log.n++;
-    if (g < depth) {  // the deepest generation spawns nothing
-      if ((rc = rec(RT355_K_SPAWN, g))) return rc;
-      // with the side stream in use, the event it waits for rides on this launch's own completion signal:
-      // a separate event record would put a marker packet, and some microseconds, between spawn and trace
-      hipEvent_t done = overlap ? c->ev_traced[g] : nullptr;
-      const int any_t = s->any_transparent ? 1 : 0, launch_id = log.n;
+    const bool fused = c->fused && !quad;  // trace, slot allocation and spawn of the generation in one launch
+    const int prim = (g == 0 && primary) ? 1 : 0, any_t = s->any_transparent ? 1 : 0;
+    // with the side stream in use, the event it waits for rides on the completion signal of the generation's
+    // last launch on the main stream: a separate event record would put a marker packet, and some
+    // microseconds, between that launch and the next trace
+    hipEvent_t done = (overlap && !last) ? c->ev_traced[g] : nullptr;
+    if (fused && !last) {
+      // grid: one block per chunk up to the cap; beyond it a block takes several chunks per slot allocation
+      const uint32_t fgrid = std::min<uint32_t>(grid, c->fused_grid);
       if (packet)
-        hipExtLaunchKernelGGL((k_spawn<R, COUNT, true>), dim3(grid), dim3(block), 0, c->stream, nullptr, done, 0, sc, pool, ctl, g, any_t, launch_id);
+        hipExtLaunchKernelGGL((k_trace_spawn<R, COUNT, true>), dim3(fgrid), dim3(block), 0, c->stream, nullptr, done, 0, sc, pool, ctl, g, depth - g, log.n, cam, prim, any_t);
       else
-        hipExtLaunchKernelGGL((k_spawn<R, COUNT, false>), dim3(grid), dim3(block), 0, c->stream, nullptr, done, 0, sc, pool, ctl, g, any_t, launch_id);
+        hipExtLaunchKernelGGL((k_trace_spawn<R, COUNT, false>), dim3(fgrid), dim3(block), 0, c->stream, nullptr, done, 0, sc, pool, ctl, g, depth - g, log.n, cam, prim, any_t);
       log.n++;
+    } else {
+      const int count_hits = fused ? 1 : 0;  // fused frame, deepest generation: no k_scan follows
+      if (quad)  // the deepest generation is shaded by a k_shadow_q launch of its own, below
+        hipLaunchKernelGGL((k_trace_q<R, COUNT>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n, cam, prim);
+      else if (packet && last)
+        hipLaunchKernelGGL((k_trace<R, COUNT, true, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, 0, log.n, cam, prim, count_hits);
+      else if (packet)
+        hipLaunchKernelGGL((k_trace<R, COUNT, true, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n, cam, prim, count_hits);
+      else if (last)
+        hipLaunchKernelGGL((k_trace<R, COUNT, false, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, 0, log.n, cam, prim, count_hits);
+      else
+        hipLaunchKernelGGL((k_trace<R, COUNT, false, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n, cam, prim, count_hits);
+      log.n++;
+      if (!fused) {
+        if ((rc = rec(RT355_K_SCAN, g))) return rc;
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, pool.blk_hits, pool.blk_children, pool.blk_base, ctl, g, (long long)pool.capacity);
+        log.n++;
+        if (g < depth) {  // the deepest generation spawns nothing
+          if ((rc = rec(RT355_K_SPAWN, g))) return rc;
+          const int launch_id = log.n;
+          if (packet)
+            hipExtLaunchKernelGGL((k_spawn<R, COUNT, true>), dim3(grid), dim3(block), 0, c->stream, nullptr, done, 0, sc, pool, ctl, g, any_t, launch_id);
+          else
+            hipExtLaunchKernelGGL((k_spawn<R, COUNT, false>), dim3(grid), dim3(block), 0, c->stream, nullptr, done, 0, sc, pool, ctl, g, any_t, launch_id);
+          log.n++;
+        }
+      }
     }
     // Shadow launches.  The one of generation g - lag is released here, behind the spawn of generation g:
     // the next trace then reaches the device first and the shadow waves fill the SIMDs its tail leaves
@@ -259,13 +283,16 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, uint32
       if ((rc2 = rec(RT355_K_SHADE, sg))) return rc2;
       if (sg < c->packet_gens)
         hipLaunchKernelGGL((k_shadow<R, COUNT, true>), dim3(sgrid), dim3(block), 0, st, sc, pool, ctl, sg, log.n);
+      else if (c->quad & 2)
+        hipLaunchKernelGGL((k_shadow_q<R, COUNT>), dim3(sgrid), dim3(block), 0, st, sc, pool, ctl, sg, log.n);
       else
         hipLaunchKernelGGL((k_shadow<R, COUNT, false>), dim3(sgrid), dim3(block), 0, st, sc, pool, ctl, sg, log.n);
       log.n++;
       return (int)RT355_OK;
     };
+    const bool shaded_in_trace = last && !quad;  // k_trace<..., LAST> shades its own hits
     if (!overlap) {
-      if (!last && (rc = shadow(g, c->stream))) return rc;  // the deepest generation shades inside its trace
+      if (!shaded_in_trace && (rc = shadow(g, c->stream))) return rc;
       continue;
     }
     const int lag = c->shadow_lag;
@@ -276,9 +303,12 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, uint32
       // every generation still waiting: their traces finished long ago
       for (int sg = std::max(0, g - lag); sg < g; ++sg)
         if ((rc = shadow(sg, c->side))) return rc;
+      if (!shaded_in_trace && (rc = shadow(g, c->stream))) return rc;  // behind its own trace, on the same stream
     }
   }
   log.depth = depth;
+  log.fused_last = !(depth >= c->packet_gens && (c->quad & 1));
+  log.fused = c->fused && !(c->quad & 1);
   if (overlap && depth > 0) {
     HIP_TRY(hipEventRecord(c->ev_side_done, c->side));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_side_done, 0));
@@ -344,9 +374,10 @@ int finish_stats(rt355_ctx* c, const LaunchLog& log, double frame_ms, rt355_stat
       st->launch_max_box_tests[i] = w[10];
       st->launch_max_wave_clocks[i] = w[11];
       const int g = log.gen[i];
-      if (log.kind[i] == RT355_K_SHADE || (log.kind[i] == RT355_K_TRACE && g == log.depth))
+      if (log.kind[i] == RT355_K_SHADE || (log.kind[i] == RT355_K_TRACE && g == log.depth && log.fused_last))
         fl += (F_PREPARE + F_SHADE) * (double)hits_of[g];  // over_point + lighting of every hit
-      if (log.kind[i] == RT355_K_SPAWN) fl += 0.5 * (F_REFLECT + F_REFRACT) * (double)h.gen_count[g + 1].v;
+      if (log.kind[i] == RT355_K_SPAWN || (log.kind[i] == RT355_K_TRACE && log.fused && g < log.depth))
+        fl += 0.5 * (F_REFLECT + F_REFRACT) * (double)h.gen_count[g + 1].v;
       if (log.kind[i] == RT355_K_COMBINE) fl += 8.0 * (double)hits_of[g];  // surface + refl * R + refr * (1 - R)
       st->launch_flops[i] = fl;
     }
@@ -401,7 +432,10 @@ int rays_impl(rt355_ctx* c, const rt355_scene* s, const float* rays_host, size_t
   if (trace_only) {
     DevScene<R> sc = dev_scene<R>(s);
     hipLaunchKernelGGL(k_reset_ctl, dim3(1), dim3(256), 0, c->stream, (FrameCtl*)c->ctl.p, (uint32_t)n);
-    hipLaunchKernelGGL((k_trace<R, false, false, false>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (FrameCtl*)c->ctl.p, 0, 0, 0, DevCamera<R>{}, 0);
+    if (c->quad & 1)
+      hipLaunchKernelGGL((k_trace_q<R, false>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (FrameCtl*)c->ctl.p, 0, 0, 0, DevCamera<R>{}, 0);
+    else
+      hipLaunchKernelGGL((k_trace<R, false, false, false>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (FrameCtl*)c->ctl.p, 0, 0, 0, DevCamera<R>{}, 0, 0);
     if ((rc = c->io_out.ensure(n * sizeof(double)))) return rc;
     if ((rc = c->io_out2.ensure(n * sizeof(int32_t)))) return rc;
     hipLaunchKernelGGL((k_export_hits<R>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (uint32_t)n, (double*)c->io_out.p, (int32_t*)c->io_out2.p);
@@ -552,6 +586,9 @@ int rt355_ctx_create(rt355_ctx** out, int device_id, int real_bits) {
   if (const char* e = getenv("RT355_PACKET_GENS")) c->packet_gens = std::max(0, std::min((int)RT355_MAX_GEN, atoi(e)));
   if (const char* e = getenv("RT355_COMBINE_LEVELS")) c->combine_levels = std::max(0, std::min(3, atoi(e)));
   if (const char* e = getenv("RT355_SHADOW_LAG")) c->shadow_lag = std::max(0, atoi(e));
+  if (const char* e = getenv("RT355_QUAD")) c->quad = atoi(e) & 3;
+  if (const char* e = getenv("RT355_FUSED")) c->fused = atoi(e) != 0;
+  if (const char* e = getenv("RT355_FUSED_GRID")) c->fused_grid = (uint32_t)std::max(64, std::min(1 << 20, atoi(e)));
   *out = c;
   return RT355_OK;
 }
@@ -724,8 +761,14 @@ int rt355_is_shadowed(rt355_ctx* c, const rt355_scene* s, const float* points, s
   if ((rc = c->io_in.ensure(n * 3 * sizeof(float)))) return rc;
   if ((rc = c->io_out.ensure(n))) return rc;
   HIP_TRY(hipMemcpyAsync(c->io_in.p, points, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  const unsigned grid = (unsigned)((n + 255) / 256);
-  if (c->real_bits == 32)
+  if (n >= 0x3fffffffull) return set_err(RT355_EINVAL, "too many points in one call");
+  const unsigned grid = (unsigned)((n + 255) / 256), grid_q = (unsigned)((n + QUADS - 1) / QUADS);
+  if (c->quad & 2) {  // the traversal the frame's shadow launches use
+    if (c->real_bits == 32)
+      hipLaunchKernelGGL((k_shadow_points_q<float>), dim3(grid_q), dim3(256), 0, c->stream, dev_scene<float>(s), (const float*)c->io_in.p, (uint32_t)n, (uint8_t*)c->io_out.p);
+    else
+      hipLaunchKernelGGL((k_shadow_points_q<double>), dim3(grid_q), dim3(256), 0, c->stream, dev_scene<double>(s), (const float*)c->io_in.p, (uint32_t)n, (uint8_t*)c->io_out.p);
+  } else if (c->real_bits == 32)
     hipLaunchKernelGGL((k_shadow_points<float>), dim3(grid), dim3(256), 0, c->stream, dev_scene<float>(s), (const float*)c->io_in.p, (uint32_t)n, (uint8_t*)c->io_out.p);
   else
     hipLaunchKernelGGL((k_shadow_points<double>), dim3(grid), dim3(256), 0, c->stream, dev_scene<double>(s), (const float*)c->io_in.p, (uint32_t)n, (uint8_t*)c->io_out.p);
@@ -774,6 +817,19 @@ int rt355_scene_check(const rt355_shape_desc* shapes, size_t n_shapes, int real_
   out[3] = (uint64_t)hs.max_depth, out[4] = hs.materials.size();
   return RT355_OK;
 }
+
+#ifdef RT355_EXP_STAMPS
+// Diagnostic build only: copies out and clears the per-wave traversal records (see DbgRec).
+int rt355_dbg_read(void* out, size_t bytes) {
+  const size_t all = sizeof(DbgRec) * (size_t)RT355_MAX_LAUNCH * DBG_PER_LAUNCH;
+  if (bytes < all) return (int)(all >> 20);
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), all) != hipSuccess) return -1;
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_dbg)) != hipSuccess || hipMemset(p, 0, all) != hipSuccess) return -1;
+  return 0;
+}
+#endif
 
 void rt355_flop_table(double out[16]) {
   out[0] = F_PRIMARY, out[1] = F_BOX, out[2] = F_XFORM;
