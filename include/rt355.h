@@ -171,6 +171,19 @@ int rt355_render(rt355_ctx*, const rt355_scene*, const rt355_camera_desc* cam, i
 int rt355_render_device(rt355_ctx*, const rt355_scene*, const rt355_camera_desc* cam, int max_depth,
                         float* rgb_out_dev, rt355_stats* stats /* nullable */);
 
+/* rt355_render_device for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  The frame's ray
+ * pool and control block live in a fixed workspace of RT355_NOALLOC_BYTES inside the library (one copy per
+ * GPU, held until the process ends) instead of the context's growable buffers: the call allocates and frees
+ * nothing.  A frame that needs more -- (tiles x 1024 primary rays) x pool factor x ~118 bytes in f64, ~66 in
+ * f32, i.e. about 320x200 at the default factor 8 in f64 -- is refused with RT355_ECAPACITY before any launch.
+ * Every call on a GPU shares that GPU's workspace: calls that overlap on one GPU (two contexts, two threads)
+ * race; the workspace keeps the last frame's contents, what must start at zero is cleared by the call itself.
+ * Same output and statistics as rt355_render_device. */
+#define RT355_NOALLOC_BYTES (64u << 20)
+int rt355_render_device_noalloc(rt355_ctx*, const rt355_scene*, const rt355_camera_desc* cam, int max_depth,
+                                float* rgb_out_dev, rt355_stats* stats /* nullable */);
+
 /* Same frame, rank `rank` of `n_ranks` renders only its 32x32 tiles (tile t belongs to rank
  * t % n_ranks) into DEVICE memory `tiles_out`: rt355_tiles_per_rank() * 1024 * 3 floats, tile-major,
  * pixels of a tile row-major.  With n_ranks == 1 this is the whole frame in tile order.

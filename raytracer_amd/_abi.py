@@ -95,6 +95,7 @@ SYMBOLS = [
     ("rt355_scene_info", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("rt355_render", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_void_p, C.POINTER(Stats)]),
     ("rt355_render_device", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_void_p, C.POINTER(Stats)]),
+    ("rt355_render_device_noalloc", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_void_p, C.POINTER(Stats)]),
     ("rt355_render_tiles", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(Stats)]),
     ("rt355_tiles_per_rank", C.c_int64, [C.POINTER(CameraDesc), C.c_int]),
     ("rt355_untile", C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_void_p, C.c_void_p]),

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -39,6 +40,29 @@ int set_err(int code, const std::string& msg) {
 const double F_PRIMARY = 40, F_BOX = 24, F_XFORM = 33;
 const double F_KIND[8] = {28 /*sphere*/, 4 /*plane*/, 20 /*cube*/, 50 /*cylinder*/, 62 /*cone*/, 0, 52 /*triangle*/, 52 /*smooth*/};
 const double F_SHADE = 190, F_PREPARE = 60, F_REFLECT = 30, F_REFRACT = 35, F_SCHLICK = 25;
+
+// Fixed workspace of rt355_render_device_noalloc: the frame's ray pool and control block for callers that may
+// not allocate (HIP graph capture, serving loops).  One copy per GPU the library runs on, held until the
+// process ends.  In host code the array's name is only a handle: the device address is asked for once per
+// device (scratch_address) and everything on the host side goes through that pointer.
+static __device__ __align__(256) unsigned char scratch[RT355_NOALLOC_BYTES];
+constexpr int MAX_DEVICES = 64;
+void* g_scratch_ptr[MAX_DEVICES] = {};
+std::mutex g_scratch_mutex;
+
+// Address of this device's copy of `scratch`; the device must be current.  Looked up on first use per device.
+int scratch_address(int device, void** out) {
+  if (device < 0 || device >= MAX_DEVICES) return set_err(RT355_EINVAL, "device id out of range");
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[device]) {
+    void* p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p) return set_err(RT355_EHIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+    g_scratch_ptr[device] = p;
+  }
+  *out = g_scratch_ptr[device];
+  return RT355_OK;
+}
 
 struct DevBuf {
   void* p = nullptr;
@@ -81,6 +105,7 @@ struct rt355_ctx {
   DevBuf org, dir, hit_t, hit_uv, hit_prim, color, mixr, child, blk_hits, blk_children, blk_base, ctl, io_in, io_out, io_out2;
   hipEvent_t ev[RT355_MAX_LAUNCH + 1] = {};  // timing mode: one before every launch, one behind the last
   FrameCtl* ctl_host = nullptr;  // pinned
+  void* fixed_scratch = nullptr;  // this device's copy of the fixed workspace (rt355_render_device_noalloc)
   int n_cu = 256;
 };
 
@@ -195,6 +220,33 @@ int ensure_pool(rt355_ctx* c, uint64_t n_primary, bool secondary, RayPool<R>& po
   return RT355_OK;
 }
 
+// The same pool laid out in a caller-independent fixed buffer: nothing is allocated, the capacity is whatever
+// fits.  Returns RT355_ECAPACITY when the frame needs more than the buffer holds.
+template <class R>
+int carve_pool(rt355_ctx* c, void* base, size_t bytes, uint64_t n_primary, bool secondary, RayPool<R>& pool, FrameCtl** ctl) {
+  const double factor = secondary ? std::max(1.0, c->pool_factor) : 1.0;
+  const uint64_t cap = (uint64_t)std::ceil((double)n_primary * factor) + 64;
+  const uint64_t nblk = cap / BLOCK + 2;
+  size_t off = 0;
+  auto take = [&](size_t n) {
+    void* p = (unsigned char*)base + off;
+    off += (n + 255) & ~(size_t)255;
+    return p;
+  };
+  *ctl = (FrameCtl*)take(sizeof(FrameCtl));
+  pool.org = (R*)take(cap * 3 * sizeof(R)), pool.dir = (R*)take(cap * 3 * sizeof(R));
+  pool.hit_t = (R*)take(cap * sizeof(R)), pool.hit_uv = (R*)take(cap * 2 * sizeof(R));
+  pool.hit_prim = (int32_t*)take(cap * sizeof(int32_t)), pool.color = (R*)take(cap * 3 * sizeof(R));
+  pool.mixr = (R*)take(cap * sizeof(R)), pool.child = (int32_t*)take(cap * 2 * sizeof(int32_t));
+  pool.blk_hits = (uint32_t*)take(nblk * sizeof(uint32_t)), pool.blk_children = (uint32_t*)take(nblk * sizeof(uint32_t));
+  pool.blk_base = (uint32_t*)take(nblk * sizeof(uint32_t));
+  pool.capacity = (int64_t)cap;
+  if (off > bytes)
+    return set_err(RT355_ECAPACITY, "frame too large for the fixed workspace: " + std::to_string(off) + " bytes needed, " + std::to_string(bytes) +
+                                        " available (" + std::to_string(n_primary) + " primary rays x pool factor " + std::to_string(factor) + ")");
+  return RT355_OK;
+}
+
 struct LaunchLog {
   int n = 0;
   int depth = 0;  // deepest generation
@@ -207,10 +259,9 @@ struct LaunchLog {
 // (`primary`) or already in the pool.  Leaves the combined
 // generation-0 colours in pool.color[0..n_primary).
 template <class R, bool COUNT>
-int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, uint32_t n_primary, int max_depth, const DevCamera<R>& cam, bool primary,
+int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, FrameCtl* ctl, uint32_t n_primary, int max_depth, const DevCamera<R>& cam, bool primary,
                     int out_mode, float* out_dev, LaunchLog& log) {
   DevScene<R> sc = dev_scene<R>(s);
-  FrameCtl* ctl = (FrameCtl*)c->ctl.p;
   hipLaunchKernelGGL(k_reset_ctl, dim3(1), dim3(256), 0, c->stream, ctl, n_primary);
   const int depth = s->any_secondary ? max_depth : 0;  // no reflective / transparent material: one generation
   const int block = BLOCK;
@@ -387,20 +438,26 @@ int finish_stats(rt355_ctx* c, const LaunchLog& log, double frame_ms, rt355_stat
 
 template <class R>
 int render_impl(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam, int max_depth, int rank, int n_ranks,
-                int out_mode, float* out_dev, rt355_stats* st) {
+                int out_mode, float* out_dev, rt355_stats* st, bool fixed_workspace = false) {
   DevCamera<R> dc;
   int rc = dev_camera<R>(cam, rank, n_ranks, dc);
   if (rc) return rc;
   const int64_t tpr = tiles_per_rank_of(dc.width, dc.height, n_ranks);
   const uint64_t n_primary = (uint64_t)tpr * TILE_PIX;
   RayPool<R> pool;
-  if ((rc = ensure_pool<R>(c, n_primary, s->any_secondary && max_depth > 0, pool))) return rc;
+  FrameCtl* ctl = nullptr;
+  if (fixed_workspace) {
+    if ((rc = carve_pool<R>(c, c->fixed_scratch, RT355_NOALLOC_BYTES, n_primary, s->any_secondary && max_depth > 0, pool, &ctl))) return rc;
+  } else {
+    if ((rc = ensure_pool<R>(c, n_primary, s->any_secondary && max_depth > 0, pool))) return rc;
+    ctl = (FrameCtl*)c->ctl.p;
+  }
   auto t0 = std::chrono::steady_clock::now();
   LaunchLog log;
   if (c->counting)
-    rc = run_generations<R, true>(c, s, pool, (uint32_t)n_primary, max_depth, dc, true, out_mode, out_dev, log);
+    rc = run_generations<R, true>(c, s, pool, ctl, (uint32_t)n_primary, max_depth, dc, true, out_mode, out_dev, log);
   else
-    rc = run_generations<R, false>(c, s, pool, (uint32_t)n_primary, max_depth, dc, true, out_mode, out_dev, log);
+    rc = run_generations<R, false>(c, s, pool, ctl, (uint32_t)n_primary, max_depth, dc, true, out_mode, out_dev, log);
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
   bool overflow = false;
@@ -450,9 +507,9 @@ int rays_impl(rt355_ctx* c, const rt355_scene* s, const float* rays_host, size_t
   DevCamera<R> dummy;
   memset(&dummy, 0, sizeof(dummy));
   if (c->counting)
-    rc = run_generations<R, true>(c, s, pool, (uint32_t)n, max_depth, dummy, false, (int)OUT_LINEAR, (float*)c->io_out.p, log);
+    rc = run_generations<R, true>(c, s, pool, (FrameCtl*)c->ctl.p, (uint32_t)n, max_depth, dummy, false, (int)OUT_LINEAR, (float*)c->io_out.p, log);
   else
-    rc = run_generations<R, false>(c, s, pool, (uint32_t)n, max_depth, dummy, false, (int)OUT_LINEAR, (float*)c->io_out.p, log);
+    rc = run_generations<R, false>(c, s, pool, (FrameCtl*)c->ctl.p, (uint32_t)n, max_depth, dummy, false, (int)OUT_LINEAR, (float*)c->io_out.p, log);
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(rgb_out, c->io_out.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -583,6 +640,10 @@ int rt355_ctx_create(rt355_ctx** out, int device_id, int real_bits) {
     rt355_ctx_destroy(c);
     return set_err(RT355_ENOMEM, "pinned host allocation failed");
   }
+  if (int rc = scratch_address(device_id, &c->fixed_scratch)) {  // the device is current here
+    rt355_ctx_destroy(c);
+    return rc;
+  }
   if (const char* e = getenv("RT355_PACKET_GENS")) c->packet_gens = std::max(0, std::min((int)RT355_MAX_GEN, atoi(e)));
   if (const char* e = getenv("RT355_COMBINE_LEVELS")) c->combine_levels = std::max(0, std::min(3, atoi(e)));
   if (const char* e = getenv("RT355_SHADOW_LAG")) c->shadow_lag = std::max(0, atoi(e));
@@ -706,6 +767,16 @@ int rt355_render_device(rt355_ctx* c, const rt355_scene* s, const rt355_camera_d
   if (!rgb_out_dev) return set_err(RT355_EINVAL, "null output");
   return c->real_bits == 32 ? render_impl<float>(c, s, cam, max_depth, 0, 1, OUT_ROWMAJOR, rgb_out_dev, stats)
                             : render_impl<double>(c, s, cam, max_depth, 0, 1, OUT_ROWMAJOR, rgb_out_dev, stats);
+}
+
+int rt355_render_device_noalloc(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam, int max_depth, float* rgb_out_dev, rt355_stats* stats) {
+  int rc = check_render_args(c, s, cam, max_depth);
+  if (rc) return rc;
+  if (!rgb_out_dev) return set_err(RT355_EINVAL, "null output");
+  if (!c->fixed_scratch) return set_err(RT355_EHIP, "fixed workspace address unknown");
+  // frames larger than the workspace are refused by carve_pool, before anything is launched
+  return c->real_bits == 32 ? render_impl<float>(c, s, cam, max_depth, 0, 1, OUT_ROWMAJOR, rgb_out_dev, stats, true)
+                            : render_impl<double>(c, s, cam, max_depth, 0, 1, OUT_ROWMAJOR, rgb_out_dev, stats, true);
 }
 
 int rt355_render_tiles(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam, int max_depth, int rank, int n_ranks,
