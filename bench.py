@@ -82,21 +82,12 @@ def main():
     w, h = args.width, args.height
     dev = Device.get(local_rank, args.real)
     scene = dev.upload(world)  # once, outside the timed region
-    tpr = rd.tiles_per_rank(w, h, world_size)
-    local = torch.empty(tpr * rd.TILE * rd.TILE * 3, dtype=torch.float32, device="cuda")
-    gathered = torch.empty((world_size, local.numel()), dtype=torch.float32, device="cuda") if rank == 0 else None
-    canvas = torch.empty((h, w, 3), dtype=torch.float32, device="cuda") if rank == 0 else None
-    bufs = list(gathered.unbind(0)) if rank == 0 else None
+    loop = rd.FrameLoop(scene, dev, w, h, rank, world_size, args.depth)
+    local = loop.tiles[0]
     st = Stats()
 
     def step():
-        if world_size == 1:  # one rank owns every tile: the canvas is written in place, nothing to gather
-            rd.render_canvas(scene, cam, args.depth, canvas, st)
-            return
-        rd.render_tiles(scene, cam, args.depth, rank, world_size, local, st)
-        dist.gather(local, bufs, dst=0)
-        if rank == 0:
-            rd.untile(dev, cam, world_size, gathered, canvas)
+        loop.step(cam, st)
 
     def fence():
         torch.cuda.synchronize()

@@ -197,6 +197,11 @@ int64_t rt355_tiles_per_rank(const rt355_camera_desc* cam, int n_ranks);
 int rt355_untile(rt355_ctx*, const rt355_camera_desc* cam, int n_ranks, const float* gathered_dev,
                  float* rgb_out_dev);
 
+/* The same for tile buffers already taken through Color::to_u8 (rt355_to_u8_device on each rank's tiles): a
+ * quarter of the bytes to gather when the frame is going to be a PPM (src/ppm.rs:40-46) anyway. */
+int rt355_untile_u8(rt355_ctx*, const rt355_camera_desc* cam, int n_ranks, const uint8_t* gathered_dev,
+                    uint8_t* rgb_out_dev);
+
 /* World::color_at(ray, max_depth) (src/world.rs:58-66) for caller-supplied rays: rays is n*6
  * floats (origin xyz, direction xyz; direction is used as given, not normalised), rgb_out n*3. */
 int rt355_color_at(rt355_ctx*, const rt355_scene*, const float* rays, size_t n, int max_depth,

@@ -1582,7 +1582,8 @@ __global__ void __launch_bounds__(256) k_combine(DevScene<R> sc, RayPool<R> pool
 
 
 // rank buffers (tile-major) -> row-major canvas, after the gather on rank 0
-__global__ void __launch_bounds__(256) k_untile(const float* gathered, float* out, int width, int height, int tiles_x, int n_tiles, int n_ranks, long long tiles_per_rank) {
+template <class T>
+__global__ void __launch_bounds__(256) k_untile(const T* gathered, T* out, int width, int height, int tiles_x, int n_tiles, int n_ranks, long long tiles_per_rank) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)width * height;
   if (i >= total) return;

@@ -602,6 +602,22 @@ int check_ctx(rt355_ctx* c) {
   return RT355_OK;
 }
 
+template <class T>
+int untile_impl(rt355_ctx* c, const rt355_camera_desc* cam, int n_ranks, const T* gathered_dev, T* out_dev) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!cam || !gathered_dev || !out_dev || n_ranks < 1) return set_err(RT355_EINVAL, "bad argument");
+  int w = 0, h = 0;
+  if ((rc = camera_dims(cam, w, h))) return rc;
+  const int tiles_x = (w + TILE - 1) / TILE, tiles_y = (h + TILE - 1) / TILE;
+  const long long total = (long long)w * h;
+  hipLaunchKernelGGL((k_untile<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, gathered_dev, out_dev, w, h, tiles_x,
+                     tiles_x * tiles_y, n_ranks, (long long)tiles_per_rank_of(w, h, n_ranks));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RT355_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -790,18 +806,10 @@ int rt355_render_tiles(rt355_ctx* c, const rt355_scene* s, const rt355_camera_de
 }
 
 int rt355_untile(rt355_ctx* c, const rt355_camera_desc* cam, int n_ranks, const float* gathered_dev, float* rgb_out_dev) {
-  int rc = check_ctx(c);
-  if (rc) return rc;
-  if (!cam || !gathered_dev || !rgb_out_dev || n_ranks < 1) return set_err(RT355_EINVAL, "bad argument");
-  int w = 0, h = 0;
-  if ((rc = camera_dims(cam, w, h))) return rc;
-  const int tiles_x = (w + TILE - 1) / TILE, tiles_y = (h + TILE - 1) / TILE;
-  const long long total = (long long)w * h;
-  hipLaunchKernelGGL(k_untile, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, gathered_dev, rgb_out_dev, w, h, tiles_x,
-                     tiles_x * tiles_y, n_ranks, (long long)tiles_per_rank_of(w, h, n_ranks));
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  return RT355_OK;
+  return untile_impl<float>(c, cam, n_ranks, gathered_dev, rgb_out_dev);
+}
+int rt355_untile_u8(rt355_ctx* c, const rt355_camera_desc* cam, int n_ranks, const uint8_t* gathered_dev, uint8_t* rgb_out_dev) {
+  return untile_impl<uint8_t>(c, cam, n_ranks, gathered_dev, rgb_out_dev);
 }
 
 int rt355_color_at(rt355_ctx* c, const rt355_scene* s, const float* rays, size_t n, int max_depth, float* rgb_out, rt355_stats* stats) {

@@ -39,10 +39,10 @@ def tile_pixels(width, height, rank, world_size):
     return out
 
 
-def untile_host(gathered, width, height, world_size):
+def untile_host(gathered, width, height, world_size, dtype=np.float32):
     """numpy counterpart of rt355_untile: `gathered` is (world_size, tiles_per_rank*1024*3)."""
-    g = np.asarray(gathered, dtype=np.float32).reshape(world_size, -1, TILE, TILE, 3)
-    canvas = np.zeros((height * width, 3), dtype=np.float32)
+    g = np.asarray(gathered, dtype=dtype).reshape(world_size, -1, TILE, TILE, 3)
+    canvas = np.zeros((height * width, 3), dtype=dtype)
     for r in range(world_size):
         idx = tile_pixels(width, height, r, world_size)
         ok = idx >= 0
@@ -79,6 +79,81 @@ def untile(device, camera, world_size, gathered, out_tensor):
     cd = camera.to_desc()
     _abi.check(device.lib.rt355_untile(device.handle, C.byref(cd), world_size, C.c_void_p(gathered.data_ptr()),
                                        C.c_void_p(out_tensor.data_ptr())))
+
+
+class FrameLoop:
+    """One rank's side of a frame loop: render this rank's tiles, gather them to rank 0, un-tile there.
+
+    The tile buffer is double-buffered.  With the nccl backend `dist.gather` only enqueues the send on a
+    communication stream and returns, while the library renders on a stream of its own: a rank other than 0
+    that rendered the next frame into the same buffer could overwrite tiles that are still being sent.  Each
+    buffer therefore remembers an event recorded behind its last send, and is not rendered into before that
+    event has passed (in steady state it passed a frame ago, so the wait costs nothing).  Rank 0 synchronises
+    with the gather anyway before it un-tiles.
+
+    `render` writes this rank's tiles of frame `camera` into the tensor it is given; the default calls the
+    library (CUDA tensors); tests pass their own to run the same loop on CPU tensors over gloo.
+    `as_u8`: the tiles go through Color::to_u8 on the device before the gather (a quarter of the bytes) and the
+    canvas is uint8, the body of a binary PPM.
+    """
+
+    def __init__(self, scene, device, width, height, rank, world_size, max_depth=5, group=None, tensor_device="cuda",
+                 render=None, as_u8=False):
+        import torch
+        self.scene, self.device, self.rank, self.world_size, self.group = scene, device, rank, world_size, group
+        self.width, self.height, self.max_depth, self.as_u8 = width, height, max_depth, as_u8
+        self.cuda = str(tensor_device).startswith("cuda")
+        n = tiles_per_rank(width, height, world_size) * TILE * TILE * 3
+        out_dtype = torch.uint8 if as_u8 else torch.float32
+        self.tiles = [torch.empty(n, dtype=torch.float32, device=tensor_device) for _ in range(2)]
+        self.send = [torch.empty(n, dtype=out_dtype, device=tensor_device) for _ in range(2)] if as_u8 else self.tiles
+        self.sent = [None, None]  # event behind the last send of each buffer
+        self.gathered = torch.empty((world_size, n), dtype=out_dtype, device=tensor_device) if rank == 0 else None
+        self.canvas = torch.empty((height, width, 3), dtype=out_dtype, device=tensor_device) if rank == 0 else None
+        self.frame = 0
+        self._render = render if render is not None else self._render_library
+
+    def _render_library(self, camera, out_tensor, stats):
+        render_tiles(self.scene, camera, self.max_depth, self.rank, self.world_size, out_tensor, stats)
+
+    def step(self, camera, stats=None):
+        """One frame.  Returns the canvas tensor on rank 0 (valid until the next step), None elsewhere."""
+        import torch
+        import torch.distributed as dist
+        if self.world_size == 1 and self.cuda and not self.as_u8:
+            # one rank owns every tile: the canvas is written row-major in place, nothing to gather
+            render_canvas(self.scene, camera, self.max_depth, self.canvas.view(-1), stats)
+            return self.canvas
+        k = self.frame & 1
+        self.frame += 1
+        if self.sent[k] is not None:
+            self.sent[k].synchronize()  # the send of two frames ago read this buffer
+        self._render(camera, self.tiles[k], stats)  # synchronous: the tiles are complete when it returns
+        if self.as_u8:
+            if self.cuda:
+                _abi.check(self.device.lib.rt355_to_u8_device(self.device.handle, C.c_void_p(self.tiles[k].data_ptr()), self.tiles[k].numel(),
+                                                              C.c_void_p(self.send[k].data_ptr())))
+            else:
+                from .host import Color
+                self.send[k].copy_(torch.from_numpy(Color.to_u8(self.tiles[k].numpy())))
+        if self.world_size > 1:
+            dist.gather(self.send[k], list(self.gathered.unbind(0)) if self.rank == 0 else None, dst=0, group=self.group)
+            if self.cuda and self.rank != 0:
+                self.sent[k] = torch.cuda.Event()
+                self.sent[k].record()  # torch's current stream: the nccl work is ordered behind it on that stream
+        elif self.rank == 0:
+            self.gathered[0].copy_(self.send[k])
+        if self.rank != 0:
+            return None
+        if self.cuda:
+            fn = self.device.lib.rt355_untile_u8 if self.as_u8 else self.device.lib.rt355_untile
+            torch.cuda.current_stream().synchronize()  # the gather has landed before the library's stream reads it
+            cd = camera.to_desc()
+            _abi.check(fn(self.device.handle, C.byref(cd), self.world_size, C.c_void_p(self.gathered.data_ptr()), C.c_void_p(self.canvas.data_ptr())))
+        else:
+            g = self.gathered.numpy()
+            self.canvas.copy_(torch.from_numpy(untile_host(g, self.width, self.height, self.world_size, dtype=g.dtype)))
+        return self.canvas
 
 
 def gather_canvas(local_tiles, width, height, rank, world_size, group=None, device=None, camera=None):

@@ -591,6 +591,27 @@ def test_canvas_to_u8_on_the_device(dev):
     assert Canvas(70, 45, host).to_ppm_p6().endswith(got.tobytes())
 
 
+def test_frame_loop_on_one_rank(dev):
+    """FrameLoop (what bench.py steps): with one rank the float canvas is written in place; with as_u8 the tiles
+    go through rt355_to_u8_device and rt355_untile_u8.  Both must give Camera::render's canvas."""
+    from raytracer_amd import dist as rd
+    from raytracer_amd.host import Color
+    world, cam = scenes.glass(100, 70)
+    scene = dev.upload(world)
+    try:
+        want = scene.render(cam, 5).pixels
+        loop = rd.FrameLoop(scene, dev, 100, 70, 0, 1)
+        for _ in range(3):
+            got = loop.step(cam).cpu().numpy()
+            assert np.array_equal(got, want)
+        loop8 = rd.FrameLoop(scene, dev, 100, 70, 0, 1, as_u8=True)
+        for _ in range(3):
+            got8 = loop8.step(cam).cpu().numpy()
+            assert got8.dtype == np.uint8 and np.array_equal(got8, Color.to_u8(want))
+    finally:
+        scene.close()
+
+
 def test_glass_scene_at_8k(oracle):
     """The glass scene at 7680x4320, the largest frame size of the configurations (33 M primary rays, a 31 GB
     ray pool in f64; the stress scene of that configuration is rendered at this size in test_gpu_configs.py):

@@ -413,6 +413,65 @@ def test_gather_canvas_over_gloo(world_size):
     assert got.shape == (h, w, 3) and (got == want).all()
 
 
+def _frame_loop_worker(rank, world_size, port, w, h, as_u8, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        idx = rd.tile_pixels(w, h, rank, world_size)
+
+        def fake_render(frame_no, out_tensor, stats):
+            # frame f: pixel value = (row-major index mod 251 + f) / 255 in every channel, padding slots poisoned
+            v = np.where(idx >= 0, ((idx % 251) + frame_no) / 255.0, -7.0).astype(np.float32)
+            out_tensor.copy_(torch.from_numpy(np.repeat(v[..., None], 3, axis=-1).reshape(-1)))
+
+        loop = rd.FrameLoop(None, None, w, h, rank, world_size, tensor_device="cpu", render=fake_render, as_u8=as_u8)
+        frames = []
+        for f in (0, 1, 2):  # three different frames back to back: both tile buffers get reused
+            out = loop.step(f)
+            if rank == 0:
+                frames.append(out.numpy().copy())
+            else:
+                assert out is None
+        if rank == 0:
+            q.put(frames)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("as_u8", [False, True])
+def test_frame_loop_over_gloo(as_u8):
+    """The loop bench.py times for N > 1 (FrameLoop.step: render tiles, gather, un-tile), on CPU tensors over
+    gloo with a stand-in renderer: consecutive DIFFERENT frames must each arrive intact on rank 0, as float
+    tiles and as tiles taken through Color::to_u8 before the gather."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    w, h, world_size = 100, 70, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_frame_loop_worker, args=(r, world_size, port, w, h, as_u8, q)) for r in range(world_size)]
+    for p in procs:
+        p.start()
+    frames = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    base = (np.arange(w * h) % 251).reshape(h, w, 1)
+    for f, got in enumerate(frames):
+        if as_u8:
+            want = np.repeat(np.clip(base + f, 0, 255), 3, axis=2).astype(np.uint8)
+            assert got.dtype == np.uint8
+        else:
+            want = np.repeat(((base + f) / 255.0).astype(np.float32), 3, axis=2)
+        assert got.shape == (h, w, 3) and (got == want).all(), f
+
+
 def test_tile_render_of_the_oracle_assembles_to_the_full_frame(oracle):
     """Tile ownership stated with the oracle: rendering each rank's pixels separately (here: windows of
     the CPU oracle) and un-tiling gives the frame rendered in one piece."""
