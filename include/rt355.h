@@ -165,6 +165,18 @@ int rt355_scene_info(const rt355_scene*, uint64_t out[5]);
 int rt355_render(rt355_ctx*, const rt355_scene*, const rt355_camera_desc* cam, int max_depth,
                  float* rgb_out, rt355_stats* stats /* nullable */);
 
+/* Camera::render followed by Color::to_u8 (src/color.rs:97-111) of every channel, on the device: rgb_out is
+ * hsize*vsize*3 BYTES of host memory, the body of a binary PPM (the values src/ppm.rs:40-46 prints).  A
+ * quarter of the bytes of rt355_render cross PCIe. */
+int rt355_render_u8(rt355_ctx*, const rt355_scene*, const rt355_camera_desc* cam, int max_depth,
+                    uint8_t* rgb_out, rt355_stats* stats /* nullable */);
+
+/* Page-locked host memory for canvases (Canvas.pixels, src/canvas.rs:8-12): the copy at the end of
+ * rt355_render / rt355_multi_render runs at full PCIe rate into such a buffer and about three times slower
+ * into pageable memory.  NULL when the allocation fails. */
+void* rt355_host_alloc(size_t bytes);
+void rt355_host_free(void*);
+
 /* Camera::render again, with the canvas left in DEVICE memory (`rgb_out_dev`: hsize*vsize*3 floats,
  * same layout as rt355_render): for callers that go on working on the GPU (tone mapping, encoding, a
  * single-GPU frame loop).  Synchronous with respect to the host. */
@@ -201,6 +213,24 @@ int rt355_untile(rt355_ctx*, const rt355_camera_desc* cam, int n_ranks, const fl
  * quarter of the bytes to gather when the frame is going to be a PPM (src/ppm.rs:40-46) anyway. */
 int rt355_untile_u8(rt355_ctx*, const rt355_camera_desc* cam, int n_ranks, const uint8_t* gathered_dev,
                     uint8_t* rgb_out_dev);
+
+/* Camera::render (src/camera.rs:74-88) on SEVERAL GPUs of one node from ONE host process: what a host that
+ * is not split into one process per GPU calls.  rt355_multi_create makes one context per listed device
+ * (real_bits as rt355_ctx_create); rt355_multi_upload replicates World { pointlight, shapes }
+ * (src/world.rs:17-20) on every device; rt355_multi_render cuts the frame into 32x32 tiles, tile t to device
+ * t % n_devices, renders them concurrently (one host thread per device), gathers the tile buffers to the
+ * first device -- RCCL send / receive over xGMI when librccl can be loaded and the devices are distinct, peer
+ * copies otherwise (rt355_multi_gather_kind tells: "rccl", "peer copies" or "none") -- un-tiles there and
+ * copies the canvas to rgb_out (hsize*vsize*3 floats of HOST memory, layout of rt355_render).  stats, when
+ * given, holds the ray counts summed over the devices and the wall time of the call.  The canvas is
+ * bit-identical to rt355_render's for any number of devices. */
+typedef struct rt355_multi rt355_multi;
+int rt355_multi_create(rt355_multi** out, const int* device_ids, int n_devices, int real_bits);
+void rt355_multi_destroy(rt355_multi*);
+int rt355_multi_upload(rt355_multi*, const rt355_shape_desc* shapes, size_t n_shapes, const rt355_light_desc* light);
+int rt355_multi_render(rt355_multi*, const rt355_camera_desc* cam, int max_depth, float* rgb_out,
+                       rt355_stats* stats /* nullable */);
+const char* rt355_multi_gather_kind(const rt355_multi*);
 
 /* World::color_at(ray, max_depth) (src/world.rs:58-66) for caller-supplied rays: rays is n*6
  * floats (origin xyz, direction xyz; direction is used as given, not normalised), rgb_out n*3. */

@@ -9,7 +9,7 @@ dist.py     tile split + canvas gather across ranks (torch.distributed)
 csrc/       HIP kernels + C ABI implementation (librt355.so)
 """
 from . import matrix  # noqa: F401
-from .host import (Camera, Canvas, Color, Device, Material, Pattern, PointLight, RefractiveIndex, Scene, Shape,  # noqa: F401
-                   World)
+from .host import (Camera, Canvas, Color, Device, Material, MultiDevice, Pattern, PointLight, RefractiveIndex, Scene,  # noqa: F401
+                   Shape, World)
 
 EPSILON = 1.0e-3  # src/epsilon.rs:1

@@ -94,6 +94,14 @@ SYMBOLS = [
     ("rt355_scene_destroy", None, [C.c_void_p]),
     ("rt355_scene_info", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("rt355_render", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_void_p, C.POINTER(Stats)]),
+    ("rt355_render_u8", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_void_p, C.POINTER(Stats)]),
+    ("rt355_host_alloc", C.c_void_p, [C.c_size_t]),
+    ("rt355_host_free", None, [C.c_void_p]),
+    ("rt355_multi_create", C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int]),
+    ("rt355_multi_destroy", None, [C.c_void_p]),
+    ("rt355_multi_upload", C.c_int, [C.c_void_p, C.POINTER(ShapeDesc), C.c_size_t, C.POINTER(LightDesc)]),
+    ("rt355_multi_render", C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_void_p, C.POINTER(Stats)]),
+    ("rt355_multi_gather_kind", C.c_char_p, [C.c_void_p]),
     ("rt355_render_device", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_void_p, C.POINTER(Stats)]),
     ("rt355_render_device_noalloc", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_void_p, C.POINTER(Stats)]),
     ("rt355_render_tiles", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(Stats)]),

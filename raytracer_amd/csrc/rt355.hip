@@ -777,6 +777,37 @@ int rt355_render(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* ca
   return RT355_OK;
 }
 
+int rt355_render_u8(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam, int max_depth, uint8_t* rgb_out, rt355_stats* stats) {
+  int rc = check_render_args(c, s, cam, max_depth);
+  if (rc) return rc;
+  if (!rgb_out) return set_err(RT355_EINVAL, "null output");
+  const size_t n = (size_t)(int)cam->hsize * (size_t)(int)cam->vsize * 3;
+  if ((rc = c->io_out.ensure(n * sizeof(float)))) return rc;
+  if ((rc = c->io_out2.ensure(n))) return rc;
+  rc = c->real_bits == 32 ? render_impl<float>(c, s, cam, max_depth, 0, 1, OUT_ROWMAJOR, (float*)c->io_out.p, stats)
+                          : render_impl<double>(c, s, cam, max_depth, 0, 1, OUT_ROWMAJOR, (float*)c->io_out.p, stats);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_to_u8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float*)c->io_out.p, n, (uint8_t*)c->io_out2.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(rgb_out, c->io_out2.p, n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RT355_OK;
+}
+
+void* rt355_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+    (void)set_err(RT355_ENOMEM, "pinned host allocation failed");
+    return nullptr;
+  }
+  return p;
+}
+void rt355_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
+int rt355_set_error(int code, const char* msg) { return set_err(code, msg ? msg : ""); }
+
 int rt355_render_device(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam, int max_depth, float* rgb_out_dev, rt355_stats* stats) {
   int rc = check_render_args(c, s, cam, max_depth);
   if (rc) return rc;

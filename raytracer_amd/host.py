@@ -329,6 +329,38 @@ class Device:
         Device._cache = {k: v for k, v in Device._cache.items() if v is not self}
 
 
+class MultiDevice:
+    """Several GPUs of one node driven by this one process (rt355_multi_*): one context and one replica of
+    the scene per device; `render` is Camera::render with the frame's tiles spread over the devices."""
+
+    def __init__(self, device_ids, real_bits=64):
+        self.lib = _abi.lib()
+        self.handle = C.c_void_p()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        _abi.check(self.lib.rt355_multi_create(C.byref(self.handle), ids, len(device_ids), real_bits))
+        self.n_devices, self.real_bits = len(device_ids), real_bits
+
+    def gather_kind(self):
+        return self.lib.rt355_multi_gather_kind(self.handle).decode()
+
+    def upload(self, world):
+        light = world.pointlight.to_desc()
+        _abi.check(self.lib.rt355_multi_upload(self.handle, world.descs(), world.n_shapes(), C.byref(light)))
+
+    def render(self, camera, max_depth=5, stats=None):
+        w, h = int(camera.horizontal_size), int(camera.vertical_size)
+        out = np.empty((h, w, 3), dtype=np.float32)
+        cd = camera.to_desc()
+        _abi.check(self.lib.rt355_multi_render(self.handle, C.byref(cd), max_depth, out.ctypes.data,
+                                               C.byref(stats) if stats is not None else None))
+        return Canvas(w, h, out)
+
+    def close(self):
+        if self.handle:
+            self.lib.rt355_multi_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
 class Scene:
     """Device-resident World: shape tables + BVH, built once by rt355_scene_upload."""
 
@@ -353,6 +385,15 @@ class Scene:
         _abi.check(self.lib.rt355_render(self.device.handle, self.handle, C.byref(cd), max_depth, out.ctypes.data,
                                          C.byref(stats) if stats is not None else None))
         return Canvas(w, h, out)
+
+    def render_u8(self, camera, max_depth=5, stats=None):
+        """Camera::render + Color::to_u8 on the device: (height, width, 3) uint8, the body of a binary PPM."""
+        w, h = int(camera.horizontal_size), int(camera.vertical_size)
+        out = np.empty((h, w, 3), dtype=np.uint8)
+        cd = camera.to_desc()
+        _abi.check(self.lib.rt355_render_u8(self.device.handle, self.handle, C.byref(cd), max_depth, out.ctypes.data,
+                                            C.byref(stats) if stats is not None else None))
+        return out
 
     def color_at(self, rays, max_depth=5, stats=None):
         r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)

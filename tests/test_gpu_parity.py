@@ -612,6 +612,60 @@ def test_frame_loop_on_one_rank(dev):
         scene.close()
 
 
+@pytest.mark.parametrize("real_bits", [64, 32])
+def test_multi_device_render_from_one_process(real_bits):
+    """rt355_multi_*: the frame's tiles spread over several contexts driven by one process, one host thread per
+    context, gathered to the first and un-tiled there.  A one-GPU box lists its device several times, which
+    walks everything but the RCCL calls (the gather then uses device-to-device copies); the canvas must be
+    bit-identical to rt355_render's for every device count, and the ray counts must add up."""
+    from raytracer_amd import MultiDevice
+    world, cam = scenes.glass(200, 150)
+    dev = Device.get(0, real_bits)
+    scene = dev.upload(world)
+    st1 = Stats()
+    want = scene.render(cam, 5, st1).pixels
+    scene.close()
+    for ids in ([0], [0, 0], [0, 0, 0]):
+        multi = MultiDevice(ids, real_bits)
+        try:
+            assert multi.gather_kind() == ("none" if len(ids) == 1 else "peer copies")
+            multi.upload(world)
+            st = Stats()
+            for _ in range(2):
+                got = multi.render(cam, 5, st).pixels
+                assert np.array_equal(got, want), ids
+            # generation 0 counts tile padding, which depends on the split; the rest must add up exactly
+            assert list(st.radiance_rays)[1:] == list(st1.radiance_rays)[1:] and list(st.hits) == list(st1.hits)
+            multi.upload(World.new_default())  # a second scene replaces the first on every device
+            small = Camera(40, 30, math.pi / 3, mx.view_transformation(mx.point(0, 0, -5), mx.point(0, 0, 0), mx.vector(0, 1, 0)))
+            assert np.array_equal(multi.render(small, 5).pixels, small.render(World.new_default(), 5, dev).pixels)
+        finally:
+            multi.close()
+
+
+def test_render_u8_and_pinned_canvas(dev):
+    """rt355_render_u8 = Color::to_u8 of rt355_render; rt355_render into memory from rt355_host_alloc."""
+    import ctypes as C
+    from raytracer_amd.host import Color
+    world, cam = scenes.glass(70, 45)
+    scene = dev.upload(world)
+    try:
+        want = scene.render(cam, 5).pixels
+        assert np.array_equal(scene.render_u8(cam, 5), Color.to_u8(want))
+        n = 45 * 70 * 3
+        p = dev.lib.rt355_host_alloc(n * 4)
+        assert p
+        try:
+            cd = cam.to_desc()
+            _abi.check(dev.lib.rt355_render(dev.handle, scene.handle, C.byref(cd), 5, C.c_void_p(p), None))
+            got = np.ctypeslib.as_array((C.c_float * n).from_address(p)).reshape(45, 70, 3).copy()
+        finally:
+            dev.lib.rt355_host_free(C.c_void_p(p))
+        assert np.array_equal(got, want)
+    finally:
+        scene.close()
+
+
 def test_glass_scene_at_8k(oracle):
     """The glass scene at 7680x4320, the largest frame size of the configurations (33 M primary rays, a 31 GB
     ray pool in f64; the stress scene of that configuration is rendered at this size in test_gpu_configs.py):
