@@ -70,6 +70,62 @@ int main(void) {
     assert got == want
 
 
+def _c_decls():
+    """(functions {name: n_args}, structs {name: [field names]}) of include/rt355.h."""
+    import re
+    src = open(os.path.join(ROOT, "include", "rt355.h")).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    funcs = {}
+    for m in re.finditer(r"\b(rt355_\w+)\s*\(([^;{]*?)\)\s*;", src):
+        args = m.group(2).strip()
+        funcs[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    structs = {}
+    for m in re.finditer(r"typedef struct (rt355_\w+) \{(.*?)\} \1;", src, flags=re.S):
+        fields = []
+        for decl in m.group(2).split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                name = re.sub(r"\[.*?\]", "", part).strip().split()[-1].lstrip("*")
+                fields.append(name)
+        structs[m.group(1)] = fields
+    return funcs, structs
+
+
+def test_rust_sys_crate_matches_the_header():
+    """rust/rt355-sys/src/lib.rs (what the reference's crate would link against; it cannot be compiled here, there
+    is no Rust toolchain) declares exactly the functions of include/rt355.h with the same number of arguments,
+    and its #[repr(C)] structs list the header's fields in the header's order."""
+    import re
+    rs = open(os.path.join(ROOT, "rust", "rt355-sys", "src", "lib.rs")).read()
+    rs = re.sub(r"//[^\n]*", "", rs)
+    rs_funcs = {}
+    for m in re.finditer(r"pub fn (rt355_\w+)\s*\((.*?)\)\s*(?:->[^;]*)?;", rs, flags=re.S):
+        args = m.group(2).strip()
+        rs_funcs[m.group(1)] = 0 if not args else len([a for a in args.split(",") if a.strip()])
+    rs_structs = {}
+    for m in re.finditer(r"pub struct (rt355_\w+)\s*\{(.*?)\}", rs, flags=re.S):
+        rs_structs[m.group(1)] = re.findall(r"pub (\w+)\s*:", m.group(2))
+    c_funcs, c_structs = _c_decls()
+    assert set(rs_funcs) == set(c_funcs), (sorted(set(c_funcs) - set(rs_funcs)), sorted(set(rs_funcs) - set(c_funcs)))
+    assert rs_funcs == c_funcs
+    assert set(rs_structs) == set(c_structs)
+    for name, fields in c_structs.items():
+        assert rs_structs[name] == fields, name
+    # the ctypes view is held to the same header
+    assert {n for n, _, _ in _abi.SYMBOLS} == set(c_funcs)
+    for n, _, args in _abi.SYMBOLS:
+        assert len(args) == c_funcs[n], n
+    # constants
+    for name, value in (("RT355_MAX_GEN", 8), ("RT355_MAX_LAUNCH", 48), ("RT355_ECAPACITY", -3)):
+        assert re.search(r"pub const %s: \w+ = %d;" % (name, value), rs), name
+    # every file the integration notes point at exists
+    for rel in ("rust/rt355-sys/Cargo.toml", "rust/rt355-sys/build.rs", "rust/raytracer-gpu/src/gpu.rs",
+                "rust/raytracer-gpu/src/accessors.rs", "rust/raytracer-gpu/tests/gpu_camera.rs"):
+        assert os.path.exists(os.path.join(ROOT, rel)), rel
+
+
 def test_header_is_plain_c():
     with tempfile.TemporaryDirectory() as td:
         src = os.path.join(td, "h.c")
