@@ -42,11 +42,18 @@ def cpu_baseline(world, cam, depth):
     w, h = int(cam.horizontal_size), int(cam.vertical_size)
     ww, wh = max(1, w // 4), max(1, h // 4)
     x0, y0 = (w - ww) // 2, int(h * 0.55) - wh // 2
-    _, cnt, sec = oracle.render(world, cam, depth, 32, 0, (x0, x0 + ww, y0, y0 + wh), threads=1)
+    win = (x0, x0 + ww, y0, y0 + wh)
+    _, cnt, sec = oracle.render(world, cam, depth, 32, 0, win, threads=1)
     rays = int(cnt["radiance"].sum() + cnt["hits"].sum())
+    # the same window on all the cores this job may use (rows handed out to threads): the reference itself has no
+    # threading, this is the restatement's figure, labelled so
+    n_thr = max(1, min(16, os.cpu_count() or 1))
+    _, _, sec_all = oracle.render(world, cam, depth, 32, 0, win, threads=n_thr)
     return {"value": round(rays / sec / 1e6, 6), "unit": "Mrays/s", "cores": 1, "kind": "port",
             "sample": f"{ww}x{wh} pixel window at ({x0},{y0}) of the same {w}x{h} frame, {rays} rays, "
-                      f"{sec:.1f} s, float, brute force over {world.n_shapes()} shapes, 1 thread"}
+                      f"{sec:.1f} s, float, brute force over {world.n_shapes()} shapes, 1 thread",
+            "all_cores": {"value": round(rays / sec_all / 1e6, 6), "unit": "Mrays/s", "cores": n_thr, "kind": "port (restatement, threads over rows)",
+                          "seconds": round(sec_all, 2)}}
 
 
 def main():
@@ -60,6 +67,7 @@ def main():
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--real", type=int, default=64, choices=[32, 64])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the 3840x2160 figure that is reported beside the headline")
     ap.add_argument("--rehearse", action="store_true",
                     help="all ranks on GPU 0 with the gloo backend: walks the N>1 code path on a one-GPU box (numbers are meaningless)")
     args = ap.parse_args()
@@ -137,6 +145,7 @@ def main():
                        "parallelism": f"tile{world_size}", "bvh": scene.info()},
         }
         # --- roofline of the dominant kernel: separate frames, never inside the timed region above ----
+        peak = FP64_VALU_PEAK_TFLOPS if args.real == 64 else 2 * FP64_VALU_PEAK_TFLOPS
         dev.set_timing(True)
         n_prof = 5
         acc = None
@@ -150,6 +159,7 @@ def main():
         rd.render_tiles(scene, cam, args.depth, rank, world_size, local, st)
         dev.set_counting(False)
         flops = np.array(st.launch_flops[: st.n_launch], dtype=np.float64)
+        box_flops = 24.0 * np.array(st.launch_box_tests[: st.n_launch], dtype=np.float64)  # box tests run in f32
         maxbox = list(st.launch_max_box_tests[: st.n_launch])
         rays_gen = [int(x) for x in st.radiance_rays]
         hits_gen = [int(x) for x in st.hits]
@@ -158,27 +168,43 @@ def main():
         k = int(np.argmax(ms_l))
         achieved = flops[k] / (ms_l[k] * 1e-3) / 1e12
         kernel_name = f"{KIND_NAME.get(kinds[k], '?')} generation {gens[k]}"
-        traffic = _measured_traffic(kernel_name) if (args.scene, w, h, args.depth, args.real, world_size) == ("north_star", 1920, 1080, 5, 64, 1) else None
+        headline = (args.scene, w, h, args.depth, args.real, world_size) == ("north_star", 1920, 1080, 5, 64, 1)
+        counters = _measured_counters(kernel_name) if headline else None
+        traffic = int(counters["hbm_bytes"]) if counters else None
         out["roofline"] = {
             "bound": "valu_fp64" if args.real == 64 else "valu_fp32",
             "kernel": kernel_name,
             "achieved": round(achieved, 4),
-            "peak": FP64_VALU_PEAK_TFLOPS if args.real == 64 else 2 * FP64_VALU_PEAK_TFLOPS,
+            "peak": peak,
             "unit": "TFLOP/s",
-            "frac": round(achieved / (FP64_VALU_PEAK_TFLOPS if args.real == 64 else 2 * FP64_VALU_PEAK_TFLOPS), 5),
+            "frac": round(achieved / peak, 5),
             "traffic": traffic,
             "flops_per_launch": float(flops[k]),
+            # the algorithmic count charges every unit of work to the FP64 peak; the box tests (24 FLOP each) run
+            # in single precision on purpose, so this is how much of the count is really f64 work
+            "flops_per_launch_f64_part": float(flops[k] - box_flops[k]),
+            "flops_per_launch_f32_boxes": float(box_flops[k]),
             "launch_ms": round(float(ms_l[k]), 4),
             "frame_flops": float(flops.sum()),
+            "frame_flops_f64_part": float((flops - box_flops).sum()),
             "frame_kernel_ms": round(float(ms_l.sum()), 4),
-            "frame_frac": round(float(flops.sum() / (ms_l.sum() * 1e-3) / 1e12 / (FP64_VALU_PEAK_TFLOPS if args.real == 64 else 2 * FP64_VALU_PEAK_TFLOPS)), 5),
+            # whole frame against the peak, by the wall time of the timed region (launches overlap on two streams)
+            "frame_frac": round(float(flops.sum() / (ms * 1e-3) / 1e12 / peak), 5),
             "launches": [{"kernel": KIND_NAME.get(kinds[i], "?"), "gen": gens[i], "ms": round(float(ms_l[i]), 4),
-                          "gflop": round(float(flops[i]) / 1e9, 4), "max_box_tests_one_lane": int(maxbox[i]), "max_wave_clocks": int(st.launch_max_wave_clocks[i])} for i in range(len(kinds))],
+                          "gflop": round(float(flops[i]) / 1e9, 4), "gflop_f32_boxes": round(float(box_flops[i]) / 1e9, 4),
+                          "max_box_tests_one_lane": int(maxbox[i])} for i in range(len(kinds))],
             "rays_by_generation": rays_gen, "hits_by_generation": hits_gen,
         }
-        if traffic:
+        if counters:
             gbs = traffic / (ms_l[k] * 1e-3) / 1e9
             out["roofline"]["hbm"] = {"achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4)}
+            # the same launch by the hardware's own count of FP64 vector instructions: 64 x (ADD + MUL + TRANS + 2 FMA)
+            # is an upper bound on executed FP64 FLOPs (idle lanes included), from the committed PMC passes
+            out["roofline"]["counters"] = {k2: counters[k2] for k2 in ("fp64_flops_upper_bound", "lane_utilisation", "wait_any_frac",
+                                                                       "valu_active_frac", "l2_hit_rate", "source") if k2 in counters}
+            out["roofline"]["counters"]["fp64_frac_upper_bound"] = round(counters["fp64_flops_upper_bound"] / (ms_l[k] * 1e-3) / 1e12 / peak, 5)
+        if world_size == 1 and headline and not args.no_extra:
+            out["config"]["also"] = _other_sizes(dev, scene, args)
         if not args.no_cpu_baseline and world_size == 1:
             out["cpu_baseline"] = cpu_baseline(world, cam, args.depth)
         print(json.dumps(out))
@@ -187,12 +213,47 @@ def main():
         dist.destroy_process_group()
 
 
-def _measured_traffic(kernel_name):
-    """HBM bytes of one launch of the named kernel on the headline workload, from the committed PMC passes
-    (a bench run cannot collect hardware counters itself); None when there is no such measurement."""
+def _other_sizes(dev, scene, args):
+    """The same scene at 3840x2160 (outside the timed region): where the launch chain stops dominating."""
+    w, h = 3840, 2160
+    _, cam = scenes.CONFIGS[args.scene](w, h)
+    canvas = torch.empty(h * w * 3, dtype=torch.float32, device="cuda")
+    st = Stats()
+    for _ in range(2):
+        rd.render_canvas(scene, cam, args.depth, canvas, st)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        rd.render_canvas(scene, cam, args.depth, canvas, st)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    rays = int(st.total_radiance + st.total_shadow) - (int(st.radiance_rays[0]) - w * h)
+    return {f"{args.scene} {w}x{h}": {"ms_per_frame": round(ms, 4), "rays_per_frame": rays, "mrays_per_s": round(rays / ms / 1e3, 1)}}
+
+
+def source_hash():
+    """Hash of the device sources: the committed PMC figures are only quoted for the kernels they were measured on."""
+    import hashlib
+    hsh = hashlib.sha256()
+    for name in ("kernels.h", "rt355.hip", "rt355_device.h", "scene_build.cpp"):
+        with open(os.path.join(ROOT, "raytracer_amd", "csrc", name), "rb") as fh:
+            hsh.update(fh.read())
+    return hsh.hexdigest()[:16]
+
+
+def _measured_counters(kernel_name):
+    """Hardware-counter figures of one launch of the named kernel on the headline workload, from the committed PMC
+    passes (a bench run cannot collect hardware counters itself).  None when there is no such measurement or
+    when it was taken on other kernel sources than the ones in the tree."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
-            return int(json.load(fh)["launches"][kernel_name]["bytes"])
+        with open(os.path.join(ROOT, "profiles", "r02_counters.json")) as fh:
+            doc = json.load(fh)
+        if doc.get("source_hash") != source_hash():
+            return None
+        c = dict(doc["launches"][kernel_name])
+        c["source"] = "profiles/r02_counters.json"
+        return c
     except (OSError, KeyError, ValueError):
         return None
 

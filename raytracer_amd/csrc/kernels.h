@@ -848,8 +848,8 @@ RT_FN void trace_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* 
     pool.hit_prim[r] = vis.best_p;
     if (hit) {
       pool.hit_t[r] = vis.best_t;
-      pool.hit_uv[2ull * r] = vis.best_u;
-      pool.hit_uv[2ull * r + 1] = vis.best_v;
+      if ((vis.best_flags & PF_KIND_MASK) == RT355_SMOOTH_TRIANGLE)  // the only kind whose normal reads u, v (src/shape.rs:199-203)
+        pool.hit_uv[2ull * r] = vis.best_u, pool.hit_uv[2ull * r + 1] = vis.best_v;
       if (remaining > 0) n_child = ((vis.best_flags & PF_REFLECTIVE) ? 1u : 0u) + ((vis.best_flags & PF_TRANSPARENT) ? 1u : 0u);
     }
   }
@@ -926,8 +926,8 @@ __global__ void __launch_bounds__(256, 4) k_trace_q(DevScene<R> sc, RayPool<R> p
         pool.hit_prim[r] = vis.best_p;
         if (hit) {
           pool.hit_t[r] = vis.best_t;
-          pool.hit_uv[2ull * r] = vis.best_u;
-          pool.hit_uv[2ull * r + 1] = vis.best_v;
+          if ((vis.best_flags & PF_KIND_MASK) == RT355_SMOOTH_TRIANGLE)
+            pool.hit_uv[2ull * r] = vis.best_u, pool.hit_uv[2ull * r + 1] = vis.best_v;
         } else if (remaining == 0) {
           // deepest generation: no combine launch of its own will visit this ray, its parent reads the colour
           // as it is (src/world.rs:61-63: a miss is black)

@@ -39,7 +39,8 @@ int set_err(int code, const std::string& msg) {
 // FLOP weights per unit of work: 1 per add/sub/mul/div/sqrt/min/max/compare, FMA = 2.
 const double F_PRIMARY = 40, F_BOX = 24, F_XFORM = 33;
 const double F_KIND[8] = {28 /*sphere*/, 4 /*plane*/, 20 /*cube*/, 50 /*cylinder*/, 62 /*cone*/, 0, 52 /*triangle*/, 52 /*smooth*/};
-const double F_SHADE = 190, F_PREPARE = 60, F_REFLECT = 30, F_REFRACT = 35, F_SCHLICK = 25;
+// F_SHADE: prepare_computation + Phong lighting + pattern per hit, 150, plus the pow of the specular term, 40.
+const double F_SHADE = 190, F_REFLECT = 30, F_REFRACT = 35, F_SCHLICK = 25;
 
 // Fixed workspace of rt355_render_device_noalloc: the frame's ray pool and control block for callers that may
 // not allocate (HIP graph capture, serving loops).  One copy per GPU the library runs on, held until the
@@ -426,7 +427,7 @@ int finish_stats(rt355_ctx* c, const LaunchLog& log, double frame_ms, rt355_stat
       st->launch_max_wave_clocks[i] = w[11];
       const int g = log.gen[i];
       if (log.kind[i] == RT355_K_SHADE || (log.kind[i] == RT355_K_TRACE && g == log.depth && log.fused_last))
-        fl += (F_PREPARE + F_SHADE) * (double)hits_of[g];  // over_point + lighting of every hit
+        fl += F_SHADE * (double)hits_of[g];  // over_point + lighting of every hit
       if (log.kind[i] == RT355_K_SPAWN || (log.kind[i] == RT355_K_TRACE && log.fused && g < log.depth))
         fl += 0.5 * (F_REFLECT + F_REFRACT) * (double)h.gen_count[g + 1].v;
       if (log.kind[i] == RT355_K_COMBINE) fl += 8.0 * (double)hits_of[g];  // surface + refl * R + refr * (1 - R)
