@@ -8,7 +8,9 @@ shadows, reflection / refraction depth 5, 1920x1080 -- on N MI355X of one node.
 
 A step is ONE frame: every rank renders its 32x32 tiles (tile t -> rank t % N, scene replicated), the
 rank tile buffers are gathered to rank 0 (torch.distributed.gather = RCCL over xGMI) and un-tiled there;
-with one rank the canvas is written row-major in place (same kernels, no gather).
+with one rank the canvas is written row-major in place (same kernels, no gather).  Frames are pipelined:
+--in-flight K (default 3) frames are in flight on every GPU, a step begins one frame and completes the one
+begun K steps earlier, and the timed region ends with a flush, so it holds exactly `steps` complete frames.
 The scene is uploaded once, before the timed region; all inputs are resident in HBM when timing starts.
 Rank 0 prints one JSON line.  `value` counts the rays actually traced: one radiance ray per color_at
 call plus one shadow ray per hit (src/world.rs:58-66, :105), summed over all ranks.
@@ -66,6 +68,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--real", type=int, default=64, choices=[32, 64])
+    ap.add_argument("--in-flight", type=int, default=3, help="frames kept in flight on each GPU (1: every step waits for its own frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the 3840x2160 figure that is reported beside the headline")
     ap.add_argument("--rehearse", action="store_true",
@@ -90,8 +93,11 @@ def main():
     w, h = args.width, args.height
     dev = Device.get(local_rank, args.real)
     scene = dev.upload(world)  # once, outside the timed region
-    loop = rd.FrameLoop(scene, dev, w, h, rank, world_size, args.depth)
-    local = loop.tiles[0]
+    # K frames are kept in flight on each GPU (one context per frame in flight): every step begins a frame and
+    # completes the one begun K steps earlier; the flush before each fence completes the rest, so exactly
+    # `steps` whole frames (render + gather + un-tile) lie between the two fences.
+    loop = rd.FrameLoop(scene, dev, w, h, rank, world_size, args.depth, in_flight=args.in_flight)
+    local = torch.empty(rd.tiles_per_rank(w, h, world_size) * rd.TILE * rd.TILE * 3, dtype=torch.float32, device="cuda")
     st = Stats()
 
     def step():
@@ -105,12 +111,19 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    loop.flush(st)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    loop.flush(st)
     fence()
     elapsed = time.perf_counter() - t0
+    # one frame alone, begun and waited for (no other frame in flight): the latency beside the rate
+    t1 = time.perf_counter()
+    for _ in range(5):
+        rd.render_tiles(scene, cam, args.depth, rank, world_size, local, st)
+    single_ms = (time.perf_counter() - t1) / 5 * 1e3
     rays_local = int(st.total_radiance + st.total_shadow) - (int(st.radiance_rays[0]) - _active_pixels(w, h, rank, world_size))
     primary_local = _active_pixels(w, h, rank, world_size)
 
@@ -142,7 +155,8 @@ def main():
                        else f"{args.scene} {w}x{h} depth {args.depth}",
                        "shapes": world.n_shapes(), "rays_per_frame": rays_frame, "primary_rays_per_frame": primary_frame,
                        "primary_mrays_per_s": round(primary_frame / (ms * 1e-3) / 1e6, 3),
-                       "parallelism": f"tile{world_size}", "bvh": scene.info()},
+                       "parallelism": f"tile{world_size}", "frames_in_flight": loop.K, "single_frame_ms": round(single_ms, 4),
+                       "bvh": scene.info()},
         }
         # --- roofline of the dominant kernel: separate frames, never inside the timed region above ----
         peak = FP64_VALU_PEAK_TFLOPS if args.real == 64 else 2 * FP64_VALU_PEAK_TFLOPS

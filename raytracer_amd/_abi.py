@@ -15,6 +15,7 @@ SPHERE, PLANE, CUBE, CYLINDER, CONE, GROUP, TRIANGLE, SMOOTH_TRIANGLE = range(8)
 PATTERN_NONE, PATTERN_STRIPE, PATTERN_GRADIENT, PATTERN_RING, PATTERN_CHECKER, PATTERN_TEST = range(6)
 
 K_TRACE, K_SHADE, K_COMBINE, K_SPAWN, K_SCAN = 1, 2, 3, 5, 6
+CTX_ONE_STREAM = 1
 
 
 class MaterialDesc(C.Structure):
@@ -85,6 +86,7 @@ SYMBOLS = [
     ("rt355_last_error", C.c_char_p, []),
     ("rt355_version", C.c_int, []),
     ("rt355_ctx_create", C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
+    ("rt355_ctx_create_ex", C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
     ("rt355_ctx_destroy", None, [C.c_void_p]),
     ("rt355_ctx_set_pool", C.c_int, [C.c_void_p, C.c_double]),
     ("rt355_ctx_set_exact_cones", C.c_int, [C.c_void_p, C.c_int]),
@@ -105,6 +107,9 @@ SYMBOLS = [
     ("rt355_render_device", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_void_p, C.POINTER(Stats)]),
     ("rt355_render_device_noalloc", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_void_p, C.POINTER(Stats)]),
     ("rt355_render_tiles", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(Stats)]),
+    ("rt355_render_tiles_begin", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ("rt355_render_device_begin", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_void_p]),
+    ("rt355_frame_end", C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     ("rt355_tiles_per_rank", C.c_int64, [C.POINTER(CameraDesc), C.c_int]),
     ("rt355_untile", C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_void_p, C.c_void_p]),
     ("rt355_untile_u8", C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_void_p, C.c_void_p]),

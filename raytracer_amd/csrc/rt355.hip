@@ -88,6 +88,14 @@ struct DevBuf {
 
 }  // namespace
 
+struct LaunchLog {
+  int n = 0;
+  int depth = 0;  // deepest generation
+  bool fused = false;      // k_trace_spawn launches: a trace launch also allocates and writes the child rays
+  bool fused_last = true;  // its trace launch also shades (k_trace<..., LAST>); false: a shadow launch of its own
+  int kind[RT355_MAX_LAUNCH], gen[RT355_MAX_LAUNCH];
+};
+
 struct rt355_ctx {
   int device = 0;
   int real_bits = 64;
@@ -100,6 +108,7 @@ struct rt355_ctx {
   int packet_gens = 1;  // generations 0..packet_gens-1 use the wave-packet traversal (primary rays and their shadow rays)
   int combine_levels = 2;  // generations folded into the first combine launch by walking ray subtrees (0..3)
   int shadow_lag = 0;   // the shadow launch of generation g is released behind the spawn of generation g + lag
+  int use_side = 1;     // shadow launches on the side stream (0: everything on the main stream, e.g. with several frames in flight)
   int quad = 0;         // generations beyond packet_gens, four lanes to a ray instead of one: bit 0 k_trace_q, bit 1 k_shadow_q
   int fused = 0;        // k_trace_spawn: trace + slot allocation + spawn of a generation in one launch (0: k_trace, k_scan, k_spawn)
   uint32_t fused_grid = 4096;  // blocks of a k_trace_spawn launch at most; larger generations take several chunks per block
@@ -107,11 +116,16 @@ struct rt355_ctx {
   hipEvent_t ev[RT355_MAX_LAUNCH + 1] = {};  // timing mode: one before every launch, one behind the last
   FrameCtl* ctl_host = nullptr;  // pinned
   void* fixed_scratch = nullptr;  // this device's copy of the fixed workspace (rt355_render_device_noalloc)
+  // a frame begun with rt355_render_tiles_begin and not yet ended: its launches are queued, nothing was waited for
+  bool pending = false;
+  LaunchLog pending_log;
+  std::chrono::steady_clock::time_point pending_t0;
+  double pending_primary_flops = 0;
   int n_cu = 256;
 };
 
 struct rt355_scene {
-  rt355_ctx* ctx = nullptr;
+  int device = 0;  // the scene's tables live on this device; any context of the device may render it
   int real_bits = 64;
   DevBuf nodes, prim_info, xform, tri, trin, materials;
   int32_t n_nodes = 0, n_bounded = 0, n_prims = 0, n_materials = 0, max_depth = 0;
@@ -248,13 +262,6 @@ int carve_pool(rt355_ctx* c, void* base, size_t bytes, uint64_t n_primary, bool 
   return RT355_OK;
 }
 
-struct LaunchLog {
-  int n = 0;
-  int depth = 0;  // deepest generation
-  bool fused = false;      // k_trace_spawn launches: a trace launch also allocates and writes the child rays
-  bool fused_last = true;  // its trace launch also shades (k_trace<..., LAST>); false: a shadow launch of its own
-  int kind[RT355_MAX_LAUNCH], gen[RT355_MAX_LAUNCH];
-};
 
 // The frame.  Generation 0 (ids 0..n_primary) is either made from the camera by the first trace launch
 // (`primary`) or already in the pool.  Leaves the combined
@@ -275,7 +282,7 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, FrameC
   };
   // Shadow rays feed nothing but k_combine, so they leave the critical path: with per-launch timing or
   // counting off they run on the side stream.
-  const bool overlap = !c->timing && !COUNT;
+  const bool overlap = !c->timing && !COUNT && c->use_side;
   for (int g = 0; g <= depth; ++g) {
     // generation g > 0 can hold at most twice the hits of g-1; its size is only known on the device
     const uint32_t grid = g == 0 ? grid0 : std::min<uint32_t>(grid_cap, (uint32_t)((pool.capacity + BLOCK - 1) / BLOCK));
@@ -437,9 +444,25 @@ int finish_stats(rt355_ctx* c, const LaunchLog& log, double frame_ms, rt355_stat
   return RT355_OK;
 }
 
+// Waits for the frame queued on the context, then reads its statistics and its overflow flag.
+int end_frame(rt355_ctx* c, rt355_stats* st) {
+  if (!c->pending) return set_err(RT355_EINVAL, "no frame in flight on this context");
+  c->pending = false;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c->pending_t0).count();
+  bool overflow = false;
+  int rc = finish_stats(c, c->pending_log, ms, st, &overflow);
+  if (rc) return rc;
+  // primary-ray generation is charged to the first trace launch; padding pixels are not counted
+  if (st && c->counting && st->n_launch > 0) st->launch_flops[0] += c->pending_primary_flops;
+  if (overflow) return set_err(RT355_ECAPACITY, "secondary-ray pool exhausted: raise rt355_ctx_set_pool");
+  return RT355_OK;
+}
+
 template <class R>
 int render_impl(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam, int max_depth, int rank, int n_ranks,
-                int out_mode, float* out_dev, rt355_stats* st, bool fixed_workspace = false) {
+                int out_mode, float* out_dev, rt355_stats* st, bool fixed_workspace = false, bool begin_only = false) {
+  if (c->pending) return set_err(RT355_EINVAL, "a frame begun on this context has not been ended (rt355_frame_end)");
   DevCamera<R> dc;
   int rc = dev_camera<R>(cam, rank, n_ranks, dc);
   if (rc) return rc;
@@ -461,16 +484,9 @@ int render_impl(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam
     rc = run_generations<R, false>(c, s, pool, ctl, (uint32_t)n_primary, max_depth, dc, true, out_mode, out_dev, log);
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
-  bool overflow = false;
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  if ((rc = finish_stats(c, log, ms, st, &overflow))) return rc;
-  if (st && c->counting && st->n_launch > 0) {
-    // primary-ray generation is charged to the first trace launch; padding pixels are not counted
-    st->launch_flops[0] += F_PRIMARY * (double)dc.width * dc.height / n_ranks;
-  }
-  if (overflow) return set_err(RT355_ECAPACITY, "secondary-ray pool exhausted: raise rt355_ctx_set_pool");
-  return RT355_OK;
+  c->pending = true, c->pending_log = log, c->pending_t0 = t0;
+  c->pending_primary_flops = F_PRIMARY * (double)dc.width * dc.height / n_ranks;
+  return begin_only ? RT355_OK : end_frame(c, st);
 }
 
 template <class R>
@@ -626,8 +642,11 @@ extern "C" {
 const char* rt355_last_error(void) { return g_err.c_str(); }
 int rt355_version(void) { return RT355_VERSION; }
 
-int rt355_ctx_create(rt355_ctx** out, int device_id, int real_bits) {
+int rt355_ctx_create(rt355_ctx** out, int device_id, int real_bits) { return rt355_ctx_create_ex(out, device_id, real_bits, 0); }
+
+int rt355_ctx_create_ex(rt355_ctx** out, int device_id, int real_bits, int flags) {
   if (!out) return set_err(RT355_EINVAL, "null out pointer");
+  if (flags & ~RT355_CTX_ONE_STREAM) return set_err(RT355_EINVAL, "unknown context flag");
   *out = nullptr;
   if (real_bits != 32 && real_bits != 64) return set_err(RT355_EINVAL, "real_bits must be 32 or 64");
   int n = 0;
@@ -643,6 +662,10 @@ int rt355_ctx_create(rt355_ctx** out, int device_id, int real_bits) {
   // the frame).
   int prio_least = 0, prio_greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  // One-stream contexts are meant to be used several at a time on one GPU (frames in flight): all their
+  // launches go to one stream of default priority, so that the frames share the device evenly and each context
+  // occupies one hardware queue instead of two (measured: three such frames in flight give the best rate).
+  if (flags & RT355_CTX_ONE_STREAM) prio_least = prio_greatest = 0, c->use_side = 0;
   bool ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
             hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_least) == hipSuccess;
   for (int i = 0; i <= RT355_MAX_LAUNCH && ok; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
@@ -725,7 +748,7 @@ int rt355_scene_upload(rt355_ctx* c, const rt355_shape_desc* shapes, size_t n_sh
   rc = build_host_scene(shapes, n_shapes, pad_rel, c->exact_cones ? INT64_MAX : 32, hs, err, sizeof(err));
   if (rc) return set_err(rc, err);
   rt355_scene* s = new rt355_scene();
-  s->ctx = c, s->real_bits = c->real_bits;
+  s->device = c->device, s->real_bits = c->real_bits;
   for (int k = 0; k < 3; ++k) s->light_pos[k] = light->position[k], s->light_int[k] = light->intensity[k];
   rc = c->real_bits == 32 ? upload_impl<float>(c, hs, s) : upload_impl<double>(c, hs, s);
   if (rc) {
@@ -738,7 +761,7 @@ int rt355_scene_upload(rt355_ctx* c, const rt355_shape_desc* shapes, size_t n_sh
 
 void rt355_scene_destroy(rt355_scene* s) {
   if (!s) return;
-  if (s->ctx) (void)hipSetDevice(s->ctx->device);
+  (void)hipSetDevice(s->device);
   for (DevBuf* b : {&s->nodes, &s->prim_info, &s->xform, &s->tri, &s->trin, &s->materials}) b->release();
   delete s;
 }
@@ -759,10 +782,33 @@ static int check_render_args(rt355_ctx* c, const rt355_scene* s, const rt355_cam
   int rc = check_ctx(c);
   if (rc) return rc;
   if (!s || !cam) return set_err(RT355_EINVAL, "null argument");
-  if (s->ctx != c) return set_err(RT355_EINVAL, "scene belongs to another context");
+  if (s->device != c->device || s->real_bits != c->real_bits) return set_err(RT355_EINVAL, "scene was uploaded on another device or for another precision");
   if (max_depth < 0 || max_depth >= RT355_MAX_GEN) return set_err(RT355_EINVAL, "max_depth must be in [0,7]");
   int w = 0, h = 0;
   return camera_dims(cam, w, h);
+}
+
+int rt355_render_tiles_begin(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam, int max_depth, int rank, int n_ranks, float* tiles_out_dev) {
+  int rc = check_render_args(c, s, cam, max_depth);
+  if (rc) return rc;
+  if (!tiles_out_dev) return set_err(RT355_EINVAL, "null output");
+  if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return set_err(RT355_EINVAL, "bad rank / n_ranks");
+  return c->real_bits == 32 ? render_impl<float>(c, s, cam, max_depth, rank, n_ranks, OUT_TILES, tiles_out_dev, nullptr, false, true)
+                            : render_impl<double>(c, s, cam, max_depth, rank, n_ranks, OUT_TILES, tiles_out_dev, nullptr, false, true);
+}
+
+int rt355_render_device_begin(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam, int max_depth, float* rgb_out_dev) {
+  int rc = check_render_args(c, s, cam, max_depth);
+  if (rc) return rc;
+  if (!rgb_out_dev) return set_err(RT355_EINVAL, "null output");
+  return c->real_bits == 32 ? render_impl<float>(c, s, cam, max_depth, 0, 1, OUT_ROWMAJOR, rgb_out_dev, nullptr, false, true)
+                            : render_impl<double>(c, s, cam, max_depth, 0, 1, OUT_ROWMAJOR, rgb_out_dev, nullptr, false, true);
+}
+
+int rt355_frame_end(rt355_ctx* c, rt355_stats* stats) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  return end_frame(c, stats);
 }
 
 int rt355_render(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam, int max_depth, float* rgb_out, rt355_stats* stats) {
@@ -848,7 +894,7 @@ int rt355_color_at(rt355_ctx* c, const rt355_scene* s, const float* rays, size_t
   int rc = check_ctx(c);
   if (rc) return rc;
   if (!s || (!rays && n) || (!rgb_out && n)) return set_err(RT355_EINVAL, "null argument");
-  if (s->ctx != c) return set_err(RT355_EINVAL, "scene belongs to another context");
+  if (s->device != c->device || s->real_bits != c->real_bits) return set_err(RT355_EINVAL, "scene was uploaded on another device or for another precision");
   if (max_depth < 0 || max_depth >= RT355_MAX_GEN) return set_err(RT355_EINVAL, "max_depth must be in [0,7]");
   return c->real_bits == 32 ? rays_impl<float>(c, s, rays, n, max_depth, false, rgb_out, nullptr, nullptr, stats)
                             : rays_impl<double>(c, s, rays, n, max_depth, false, rgb_out, nullptr, nullptr, stats);
@@ -858,7 +904,7 @@ int rt355_trace_sample(rt355_ctx* c, const rt355_scene* s, const float* rays, si
   int rc = check_ctx(c);
   if (rc) return rc;
   if (!s || (!rays && n) || ((!t_out || !shape_index_out) && n)) return set_err(RT355_EINVAL, "null argument");
-  if (s->ctx != c) return set_err(RT355_EINVAL, "scene belongs to another context");
+  if (s->device != c->device || s->real_bits != c->real_bits) return set_err(RT355_EINVAL, "scene was uploaded on another device or for another precision");
   return c->real_bits == 32 ? rays_impl<float>(c, s, rays, n, 0, true, nullptr, t_out, shape_index_out, nullptr)
                             : rays_impl<double>(c, s, rays, n, 0, true, nullptr, t_out, shape_index_out, nullptr);
 }
@@ -867,7 +913,7 @@ int rt355_is_shadowed(rt355_ctx* c, const rt355_scene* s, const float* points, s
   int rc = check_ctx(c);
   if (rc) return rc;
   if (!s || (!points && n) || (!out && n)) return set_err(RT355_EINVAL, "null argument");
-  if (s->ctx != c) return set_err(RT355_EINVAL, "scene belongs to another context");
+  if (s->device != c->device || s->real_bits != c->real_bits) return set_err(RT355_EINVAL, "scene was uploaded on another device or for another precision");
   if (n == 0) return RT355_OK;
   if ((rc = c->io_in.ensure(n * 3 * sizeof(float)))) return rc;
   if ((rc = c->io_out.ensure(n))) return rc;

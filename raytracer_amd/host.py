@@ -288,10 +288,10 @@ class Device:
 
     _cache = {}
 
-    def __init__(self, device_id=0, real_bits=64):
+    def __init__(self, device_id=0, real_bits=64, flags=0):
         self.lib = _abi.lib()
         self.handle = C.c_void_p()
-        _abi.check(self.lib.rt355_ctx_create(C.byref(self.handle), device_id, real_bits))
+        _abi.check(self.lib.rt355_ctx_create_ex(C.byref(self.handle), device_id, real_bits, flags))
         self.device_id, self.real_bits = device_id, real_bits
 
     @classmethod

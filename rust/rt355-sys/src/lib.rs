@@ -13,6 +13,7 @@ pub const RT355_ENOMEM: c_int = -4;
 pub const RT355_MAX_GEN: usize = 8;
 pub const RT355_MAX_LAUNCH: usize = 48;
 pub const RT355_NOALLOC_BYTES: usize = 64 << 20;
+pub const RT355_CTX_ONE_STREAM: c_int = 1;
 
 // enum rt355_kind: position in `enum Shape` (src/shape.rs:11-20)
 pub const RT355_SPHERE: i32 = 0;
@@ -107,6 +108,7 @@ extern "C" {
     pub fn rt355_last_error() -> *const c_char;
     pub fn rt355_version() -> c_int;
     pub fn rt355_ctx_create(out: *mut *mut rt355_ctx, device_id: c_int, real_bits: c_int) -> c_int;
+    pub fn rt355_ctx_create_ex(out: *mut *mut rt355_ctx, device_id: c_int, real_bits: c_int, flags: c_int) -> c_int;
     pub fn rt355_ctx_destroy(ctx: *mut rt355_ctx);
     pub fn rt355_ctx_set_pool(ctx: *mut rt355_ctx, rays_per_pixel: f64) -> c_int;
     pub fn rt355_ctx_set_exact_cones(ctx: *mut rt355_ctx, mode: c_int) -> c_int;
@@ -129,6 +131,11 @@ extern "C" {
     pub fn rt355_render_tiles(ctx: *mut rt355_ctx, scene: *const rt355_scene, cam: *const rt355_camera_desc,
                               max_depth: c_int, rank: c_int, n_ranks: c_int, tiles_out_dev: *mut f32,
                               stats: *mut rt355_stats) -> c_int;
+    pub fn rt355_render_tiles_begin(ctx: *mut rt355_ctx, scene: *const rt355_scene, cam: *const rt355_camera_desc,
+                                    max_depth: c_int, rank: c_int, n_ranks: c_int, tiles_out_dev: *mut f32) -> c_int;
+    pub fn rt355_render_device_begin(ctx: *mut rt355_ctx, scene: *const rt355_scene, cam: *const rt355_camera_desc,
+                                     max_depth: c_int, rgb_out_dev: *mut f32) -> c_int;
+    pub fn rt355_frame_end(ctx: *mut rt355_ctx, stats: *mut rt355_stats) -> c_int;
     pub fn rt355_tiles_per_rank(cam: *const rt355_camera_desc, n_ranks: c_int) -> i64;
     pub fn rt355_untile(ctx: *mut rt355_ctx, cam: *const rt355_camera_desc, n_ranks: c_int,
                         gathered_dev: *const f32, rgb_out_dev: *mut f32) -> c_int;

@@ -608,6 +608,22 @@ def test_frame_loop_on_one_rank(dev):
         for _ in range(3):
             got8 = loop8.step(cam).cpu().numpy()
             assert got8.dtype == np.uint8 and np.array_equal(got8, Color.to_u8(want))
+        # frames in flight: different cameras back to back, each canvas comes back K steps later, in order
+        cams = [scenes.glass(100, 70)[1]] + [Camera(100, 70, math.pi / 3, mx.view_transformation(mx.point(0.3 * k, 1.5, -5.0), mx.point(0, 1, 0), mx.vector(0, 1, 0))) for k in range(1, 7)]
+        wants = [scene.render(c, 5).pixels for c in cams]
+        for as_u8 in (False, True):
+            loop3 = rd.FrameLoop(scene, dev, 100, 70, 0, 1, as_u8=as_u8, in_flight=3)
+            st = Stats()
+            outs = []
+            for c in cams:
+                o = loop3.step(c, st)
+                if o is not None:
+                    outs.append(o.cpu().numpy().copy())
+            outs += [o.cpu().numpy() for o in loop3.flush(st)]
+            loop3.close()
+            assert len(outs) == len(cams) and int(st.total_radiance) > 7000
+            for o, wnt in zip(outs, wants):
+                assert np.array_equal(o, Color.to_u8(wnt) if as_u8 else wnt)
     finally:
         scene.close()
 
