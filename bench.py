@@ -9,8 +9,10 @@ shadows, reflection / refraction depth 5, 1920x1080 -- on N MI355X of one node.
 A step is ONE frame: every rank renders its 32x32 tiles (tile t -> rank t % N, scene replicated), the
 rank tile buffers are gathered to rank 0 (torch.distributed.gather = RCCL over xGMI) and un-tiled there;
 with one rank the canvas is written row-major in place (same kernels, no gather).  Frames are pipelined:
---in-flight K (default 3) frames are in flight on every GPU, a step begins one frame and completes the one
-begun K steps earlier, and the timed region ends with a flush, so it holds exactly `steps` complete frames.
+--batch B frames share one launch chain (default: max(4, N), so that a rank's chain carries at least a whole
+frame's worth of tiles whatever N is) and --in-flight K (default 3) chains are in flight on every GPU; a step adds one frame and
+hands back the oldest finished one, and the timed region ends with a flush, so it holds exactly `steps`
+complete frames.
 The scene is uploaded once, before the timed region; all inputs are resident in HBM when timing starts.
 Rank 0 prints one JSON line.  `value` counts the rays actually traced: one radiance ray per color_at
 call plus one shadow ray per hit (src/world.rs:58-66, :105), summed over all ranks.
@@ -69,6 +71,7 @@ def main():
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--real", type=int, default=64, choices=[32, 64])
     ap.add_argument("--in-flight", type=int, default=3, help="frames kept in flight on each GPU (1: every step waits for its own frame)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per launch chain (0: max(4, number of GPUs))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the 3840x2160 figure that is reported beside the headline")
     ap.add_argument("--rehearse", action="store_true",
@@ -96,7 +99,7 @@ def main():
     # K frames are kept in flight on each GPU (one context per frame in flight): every step begins a frame and
     # completes the one begun K steps earlier; the flush before each fence completes the rest, so exactly
     # `steps` whole frames (render + gather + un-tile) lie between the two fences.
-    loop = rd.FrameLoop(scene, dev, w, h, rank, world_size, args.depth, in_flight=args.in_flight)
+    loop = rd.FrameLoop(scene, dev, w, h, rank, world_size, args.depth, in_flight=args.in_flight, batch=args.batch if args.batch > 0 else max(4, world_size))
     local = torch.empty(rd.tiles_per_rank(w, h, world_size) * rd.TILE * rd.TILE * 3, dtype=torch.float32, device="cuda")
     st = Stats()
 
@@ -109,6 +112,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # untimed set-up: one full chain through every context, so that each has allocated its ray pool
+    for _ in range(loop.K * loop.B):
+        step()
+    loop.flush(st)
     for _ in range(args.warmup):
         step()
     loop.flush(st)
@@ -155,7 +162,7 @@ def main():
                        else f"{args.scene} {w}x{h} depth {args.depth}",
                        "shapes": world.n_shapes(), "rays_per_frame": rays_frame, "primary_rays_per_frame": primary_frame,
                        "primary_mrays_per_s": round(primary_frame / (ms * 1e-3) / 1e6, 3),
-                       "parallelism": f"tile{world_size}", "frames_in_flight": loop.K, "single_frame_ms": round(single_ms, 4),
+                       "parallelism": f"tile{world_size}", "chains_in_flight": loop.K, "frames_per_chain": loop.B, "single_frame_ms": round(single_ms, 4),
                        "bvh": scene.info()},
         }
         # --- roofline of the dominant kernel: separate frames, never inside the timed region above ----

@@ -222,6 +222,19 @@ int rt355_render_tiles_begin(rt355_ctx*, const rt355_scene*, const rt355_camera_
 int rt355_render_device_begin(rt355_ctx*, const rt355_scene*, const rt355_camera_desc* cam, int max_depth,
                               float* rgb_out_dev); /* rt355_render_device, begun */
 int rt355_frame_end(rt355_ctx*, rt355_stats* stats /* nullable */);
+/* Several frames of ONE image size in one launch chain: Camera::render (src/camera.rs:74-88) called n_frames
+ * times, e.g. along a camera path, with the rays of all the frames traced together.  `cams` points at
+ * n_frames cameras (1 <= n_frames <= RT355_MAX_BATCH) that share hsize and vsize.  A rank of many renders
+ * few tiles per frame, too few to fill a GPU whose every kernel ends on its slowest wave; the tiles of
+ * n_frames frames fill it like one whole frame does.  tiles_out_dev: n_frames x rt355_tiles_per_rank() x 1024
+ * x 3 floats, frame after frame, each frame laid out as rt355_render_tiles lays it out.  rgb_out_dev:
+ * n_frames canvases of rt355_render_device, one after the other.  Ended by rt355_frame_end, whose statistics
+ * are the sums over the frames.  Every frame's pixels are identical to those of a call of its own. */
+#define RT355_MAX_BATCH 64
+int rt355_render_tiles_batch_begin(rt355_ctx*, const rt355_scene*, const rt355_camera_desc* cams, int n_frames,
+                                   int max_depth, int rank, int n_ranks, float* tiles_out_dev);
+int rt355_render_device_batch_begin(rt355_ctx*, const rt355_scene*, const rt355_camera_desc* cams, int n_frames,
+                                    int max_depth, float* rgb_out_dev);
 /* Number of tiles each rank owns (tile count padded up to a multiple of n_ranks). */
 int64_t rt355_tiles_per_rank(const rt355_camera_desc* cam, int n_ranks);
 /* Rank 0, after the gather: `gathered_dev` holds n_ranks consecutive rank buffers; scatters them
@@ -233,6 +246,12 @@ int rt355_untile(rt355_ctx*, const rt355_camera_desc* cam, int n_ranks, const fl
  * quarter of the bytes to gather when the frame is going to be a PPM (src/ppm.rs:40-46) anyway. */
 int rt355_untile_u8(rt355_ctx*, const rt355_camera_desc* cam, int n_ranks, const uint8_t* gathered_dev,
                     uint8_t* rgb_out_dev);
+/* The two above for the gathered rank buffers of rt355_render_tiles_batch_begin (each holds n_frames frames):
+ * rgb_out_dev receives n_frames row-major canvases, one after the other. */
+int rt355_untile_batch(rt355_ctx*, const rt355_camera_desc* cam, int n_ranks, int n_frames,
+                       const float* gathered_dev, float* rgb_out_dev);
+int rt355_untile_batch_u8(rt355_ctx*, const rt355_camera_desc* cam, int n_ranks, int n_frames,
+                          const uint8_t* gathered_dev, uint8_t* rgb_out_dev);
 
 /* Camera::render (src/camera.rs:74-88) on SEVERAL GPUs of one node from ONE host process: what a host that
  * is not split into one process per GPU calls.  rt355_multi_create makes one context per listed device

@@ -16,6 +16,7 @@ PATTERN_NONE, PATTERN_STRIPE, PATTERN_GRADIENT, PATTERN_RING, PATTERN_CHECKER, P
 
 K_TRACE, K_SHADE, K_COMBINE, K_SPAWN, K_SCAN = 1, 2, 3, 5, 6
 CTX_ONE_STREAM = 1
+MAX_BATCH = 64
 
 
 class MaterialDesc(C.Structure):
@@ -110,9 +111,13 @@ SYMBOLS = [
     ("rt355_render_tiles_begin", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("rt355_render_device_begin", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_void_p]),
     ("rt355_frame_end", C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    ("rt355_render_tiles_batch_begin", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ("rt355_render_device_batch_begin", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_int, C.c_void_p]),
     ("rt355_tiles_per_rank", C.c_int64, [C.POINTER(CameraDesc), C.c_int]),
     ("rt355_untile", C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_void_p, C.c_void_p]),
     ("rt355_untile_u8", C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_void_p, C.c_void_p]),
+    ("rt355_untile_batch", C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    ("rt355_untile_batch_u8", C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     ("rt355_color_at", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.POINTER(Stats)]),
     ("rt355_trace_sample", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     ("rt355_is_shadowed", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

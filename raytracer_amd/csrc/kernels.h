@@ -353,6 +353,69 @@ RT_FN void traverse(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work& wk,
   int spill[STACK_DEPTH - LDS_STACK];
   int sp = 0;
   int cur = 0;
+#ifdef RT355_EXP_WW
+  for (;;) {
+    // node phase: every lane walks down until it stands on a leaf, so the leaf phase below runs with as many
+    // lanes as possible (a wave pays for a phase whenever one of its lanes is in it)
+    while (cur >= 0) {
+      const BvhNode4 N = sc.nodes[cur];
+      float tlo, thi;
+      slab_interval(vis.tmin(), vis.tmax(), tlo, thi);
+      float k0, k1, k2, k3;
+      if (!slab_test(sr, N.box[0][0], N.box[0][1], N.box[0][2], N.box[0][3], N.box[0][4], N.box[0][5], tlo, thi, k0)) k0 = INFINITY;
+      if (!slab_test(sr, N.box[1][0], N.box[1][1], N.box[1][2], N.box[1][3], N.box[1][4], N.box[1][5], tlo, thi, k1)) k1 = INFINITY;
+      if (!slab_test(sr, N.box[2][0], N.box[2][1], N.box[2][2], N.box[2][3], N.box[2][4], N.box[2][5], tlo, thi, k2)) k2 = INFINITY;
+      if (!slab_test(sr, N.box[3][0], N.box[3][1], N.box[3][2], N.box[3][3], N.box[3][4], N.box[3][5], tlo, thi, k3)) k3 = INFINITY;
+      int c0 = N.c[0], c1 = N.c[1], c2 = N.c[2], c3 = N.c[3];
+      if constexpr (COUNT) wk.box += (c0 != -1) + (c1 != -1) + (c2 != -1) + (c3 != -1);
+      auto order = [](float& ka, int& ca, float& kb, int& cb) {
+        const bool sw = kb < ka;
+        const float kt = sw ? kb : ka, ku = sw ? ka : kb;
+        const int ct = sw ? cb : ca, cu = sw ? ca : cb;
+        ka = kt, kb = ku, ca = ct, cb = cu;
+      };
+      order(k0, c0, k1, c1), order(k2, c2, k3, c3), order(k0, c0, k2, c2), order(k1, c1, k3, c3), order(k1, c1, k2, c2);
+      auto push = [&](int child) {
+        if (sp < LDS_STACK) lds[sp * BLOCK] = child; else spill[sp - LDS_STACK] = child;
+        ++sp;
+      };
+      if (k3 < INFINITY) push(c3);
+      if (k2 < INFINITY) push(c2);
+      if (k1 < INFINITY) push(c1);
+      if (k0 < INFINITY) { cur = c0; continue; }
+      if (sp == 0) return;
+      --sp;
+      cur = sp < LDS_STACK ? lds[sp * BLOCK] : spill[sp - LDS_STACK];
+    }
+    {
+      const uint32_t leaf = (uint32_t)~cur;
+      const int first = (int)(leaf & LEAF_FIRST_MASK), count = (int)(leaf >> 26);
+      if (leaf & LEAF_TRI_BIT) {
+        DevTri T[LEAF_MAX];
+#pragma unroll
+        for (int k = 0; k < LEAF_MAX; ++k) T[k] = sc.tri[first + (k < count ? k : 0)];
+#pragma unroll
+        for (int k = 0; k < LEAF_MAX; ++k)
+          if (k < count) {
+            if constexpr (COUNT) wk.prim[T[k].flags & PF_KIND_MASK]++;
+            if (vis.tri(first + k, T[k])) return;
+          }
+        for (int k = LEAF_MAX; k < count; ++k) {
+          const DevTri Tk = sc.tri[first + k];
+          if constexpr (COUNT) wk.prim[Tk.flags & PF_KIND_MASK]++;
+          if (vis.tri(first + k, Tk)) return;
+        }
+      } else {
+        for (int k = 0; k < count; ++k)
+          if (vis.prim(first + k)) return;
+      }
+    }
+    if (sp == 0) return;
+    --sp;
+    cur = sp < LDS_STACK ? lds[sp * BLOCK] : spill[sp - LDS_STACK];
+  }
+}
+#else
   for (;;) {
 #ifdef RT355_EXP_STAMPS
     DbgAcc& dacc = wk.dbg;
@@ -421,6 +484,8 @@ RT_FN void traverse(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work& wk,
     cur = sp < LDS_STACK ? lds[sp * BLOCK] : spill[sp - LDS_STACK];
   }
 }
+
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Packet traversal: the 64 rays of a wave walk the BVH TOGETHER.  The current node, the stack and every
@@ -766,13 +831,17 @@ RT_FN void gen_range(const FrameCtl* ctl, int gen, long long capacity, uint32_t&
 // Primary rays: Camera::ray_for_pixel (src/camera.rs:62-72) with the inverse hoisted out of the pixel
 // loop.  Ray i of generation 0 is pixel (x,y) of this rank's tile list: 8x8 pixel blocks per wave.
 // ------------------------------------------------------------------------------------------------
+// tile_slot: the tile's place in this rank's output (frame-major over the batch); frame: which view.
 template <class R>
-RT_FN bool pixel_of(const DevCamera<R>& cam, uint32_t i, int& x, int& y, int& tile_local, int& in_tile) {
-  tile_local = (int)(i / TILE_PIX);
+RT_FN bool pixel_of(const DevCamera<R>& cam, uint32_t i, int& x, int& y, int& tile_slot, int& in_tile, int& frame) {
+  tile_slot = (int)(i / TILE_PIX);
   const int j = (int)(i % TILE_PIX);
   const int blk = j >> 6, lane = j & 63;
   const int xt = (blk & 3) * 8 + (lane & 7), yt = (blk >> 2) * 8 + (lane >> 3);
   in_tile = yt * TILE + xt;
+  int tile_local = tile_slot;
+  frame = 0;
+  if (cam.n_frames > 1) frame = tile_slot / cam.tiles_per_frame, tile_local = tile_slot - frame * cam.tiles_per_frame;
   const long long tile = (long long)tile_local * cam.n_ranks + cam.rank;
   if (tile >= cam.n_tiles) return false;
   x = (int)(tile % cam.tiles_x) * TILE + xt;
@@ -782,15 +851,18 @@ RT_FN bool pixel_of(const DevCamera<R>& cam, uint32_t i, int& x, int& y, int& ti
 
 template <class R>
 RT_FN void primary_ray(const DevCamera<R>& cam, uint32_t i, V3<R>& org, V3<R>& dir) {
-  int x, y, tl, it;
+  int x, y, ts, it, frame;
   org = {R(0), R(0), R(0)}, dir = {R(0), R(0), R(0)};  // zero direction = inactive ray (tile padding)
-  if (pixel_of(cam, i, x, y, tl, it)) {
-    const R x_offset = (R(x) + R(0.5)) * cam.pixel_size;
-    const R y_offset = (R(y) + R(0.5)) * cam.pixel_size;
-    const R world_x = cam.half_width - x_offset;
-    const R world_y = cam.half_height - y_offset;
-    const V3<R> pixel = xf_point(cam.inv, mk<R>(world_x, world_y, R(-1)));
-    org = xf_point(cam.inv, mk<R>(R(0), R(0), R(0)));
+  if (pixel_of(cam, i, x, y, ts, it, frame)) {
+    // a tile is 1024 consecutive rays, so the 64 rays of a wave share their frame: the view comes in through
+    // scalar loads
+    const DevView<R>& v = cam.n_frames > 1 ? cam.views[__builtin_amdgcn_readfirstlane(frame)] : cam.view;
+    const R x_offset = (R(x) + R(0.5)) * v.pixel_size;
+    const R y_offset = (R(y) + R(0.5)) * v.pixel_size;
+    const R world_x = v.half_width - x_offset;
+    const R world_y = v.half_height - y_offset;
+    const V3<R> pixel = xf_point(v.inv, mk<R>(world_x, world_y, R(-1)));
+    org = xf_point(v.inv, mk<R>(R(0), R(0), R(0)));
     dir = normalize(pixel - org);
   }
 }
@@ -864,7 +936,7 @@ RT_FN void trace_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* 
 // and the child bound for k_scan; with `count_hits` set it adds the hits to the generation's total itself
 // (no k_scan launch follows: the frame runs the fused kernels and this is its deepest generation).
 template <class R, bool COUNT, bool PACKET, bool LAST>
-__global__ void __launch_bounds__(256, (PACKET && !LAST) ? 4 : 3) k_trace(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch, DevCamera<R> cam, int primary, int count_hits) {
+__global__ void __launch_bounds__(256, (PACKET && !LAST) ? 4 : RT355_WPS_LANE) k_trace(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch, DevCamera<R> cam, int primary, int count_hits) {
   __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
   int* lds = PACKET ? lds_stack + (threadIdx.x >> 6) * STACK_DEPTH : lds_stack + threadIdx.x;
   uint32_t start, count;
@@ -1251,7 +1323,7 @@ RT_FN void container_indices(const DevScene<R>& sc, bool need, int p, PrimInfo i
 // One thread per ray; lanes whose ray missed idle.
 // ------------------------------------------------------------------------------------------------
 template <class R, bool COUNT, bool PACKET>
-__global__ void __launch_bounds__(256, PACKET ? 4 : 3) k_shadow(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int launch) {
+__global__ void __launch_bounds__(256, PACKET ? 4 : RT355_WPS_LANE) k_shadow(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int launch) {
   uint32_t start, gcount;
   gen_range(ctl, gen, pool.capacity, start, gcount);
   __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
@@ -1440,7 +1512,7 @@ RT_FN void spawn_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* 
 }
 
 template <class R, bool COUNT, bool PACKET>
-__global__ void __launch_bounds__(256, 3) k_spawn(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int any_transparent, int launch) {
+__global__ void __launch_bounds__(256, RT355_WPS_SPAWN) k_spawn(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int any_transparent, int launch) {
   __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
   int* lds = PACKET ? lds_stack + (threadIdx.x >> 6) * STACK_DEPTH : lds_stack + threadIdx.x;
   Work wk;
@@ -1526,13 +1598,13 @@ RT_FN void write_pixel(const DevCamera<R>& cam, uint32_t i, int mode, float* out
   if (mode == OUT_LINEAR) {
     o = (size_t)i * 3;
   } else {
-    int x, y, tl, it;
-    const bool ok = pixel_of(cam, i, x, y, tl, it);
+    int x, y, ts, it, frame;
+    const bool ok = pixel_of(cam, i, x, y, ts, it, frame);
     if (mode == OUT_ROWMAJOR) {
       if (!ok) return;
-      o = ((size_t)y * cam.width + x) * 3;
+      o = (((size_t)frame * cam.height + y) * cam.width + x) * 3;  // one canvas per frame of the batch
     } else {
-      o = ((size_t)tl * TILE_PIX + it) * 3;  // padding pixels are written as black
+      o = ((size_t)ts * TILE_PIX + it) * 3;  // padding pixels are written as black
     }
   }
   out[o] = (float)c.x, out[o + 1] = (float)c.y, out[o + 2] = (float)c.z;
@@ -1581,16 +1653,19 @@ __global__ void __launch_bounds__(256) k_combine(DevScene<R> sc, RayPool<R> pool
 
 
 
-// rank buffers (tile-major) -> row-major canvas, after the gather on rank 0
+// rank buffers (tile-major) -> row-major canvases, after the gather on rank 0.  Every rank's buffer holds
+// n_frames frames of tiles_per_rank tiles each; frame f lands in out[f * width * height ...].
 template <class T>
-__global__ void __launch_bounds__(256) k_untile(const T* gathered, T* out, int width, int height, int tiles_x, int n_tiles, int n_ranks, long long tiles_per_rank) {
+__global__ void __launch_bounds__(256) k_untile(const T* gathered, T* out, int width, int height, int tiles_x, int n_tiles, int n_ranks, long long tiles_per_rank,
+                                                int n_frames) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long total = (long long)width * height;
-  if (i >= total) return;
-  const int x = (int)(i % width), y = (int)(i / width);
+  const long long per_frame = (long long)width * height;
+  if (i >= per_frame * n_frames) return;
+  const long long f = i / per_frame, k = i - f * per_frame;
+  const int x = (int)(k % width), y = (int)(k / width);
   const long long tile = (long long)(y / TILE) * tiles_x + (x / TILE);
   const long long rank = tile % n_ranks, tl = tile / n_ranks;
-  const long long src = ((rank * tiles_per_rank + tl) * TILE_PIX + (long long)(y % TILE) * TILE + (x % TILE)) * 3;
+  const long long src = (((rank * n_frames + f) * tiles_per_rank + tl) * TILE_PIX + (long long)(y % TILE) * TILE + (x % TILE)) * 3;
   out[i * 3] = gathered[src], out[i * 3 + 1] = gathered[src + 1], out[i * 3 + 2] = gathered[src + 2];
 }
 

@@ -115,6 +115,8 @@ struct rt355_ctx {
   DevBuf org, dir, hit_t, hit_uv, hit_prim, color, mixr, child, blk_hits, blk_children, blk_base, ctl, io_in, io_out, io_out2;
   hipEvent_t ev[RT355_MAX_LAUNCH + 1] = {};  // timing mode: one before every launch, one behind the last
   FrameCtl* ctl_host = nullptr;  // pinned
+  void* views_dev = nullptr;   // the views of a batch of frames (RT355_MAX_BATCH x DevView<double>), read by generation 0
+  void* views_host = nullptr;  // pinned staging of the same
   void* fixed_scratch = nullptr;  // this device's copy of the fixed workspace (rt355_render_device_noalloc)
   // a frame begun with rt355_render_tiles_begin and not yet ended: its launches are queued, nothing was waited for
   bool pending = false;
@@ -167,7 +169,7 @@ int camera_dims(const rt355_camera_desc* c, int& w, int& h) {
 // Camera::new (src/camera.rs:23-51) in R, plus the inverse of the camera transformation that
 // ray_for_pixel recomputes per pixel (src/camera.rs:67).
 template <class R>
-int dev_camera(const rt355_camera_desc* c, int rank, int n_ranks, DevCamera<R>& out) {
+int dev_view(const rt355_camera_desc* c, DevView<R>& out) {
   int cw = 0, chh = 0;
   if (int rc = camera_dims(c, cw, chh)) return rc;
   if (!std::isfinite(c->fov)) return set_err(RT355_EINVAL, "camera: bad field of view");
@@ -196,10 +198,30 @@ int dev_camera(const rt355_camera_desc* c, int rank, int n_ranks, DevCamera<R>& 
   out.half_width = aspect >= R(1) ? half_view : half_view * aspect;
   out.half_height = aspect >= R(1) ? half_view / aspect : half_view;
   out.pixel_size = (out.half_width * R(2)) / hsize;
+  out.pad = R(0);
+  return RT355_OK;
+}
+
+// The cameras of one launch chain: n_frames views of one image size.  The views of a batch (n_frames > 1) are
+// written to `views_host`, which the caller copies to the device address it stores in out.views.
+template <class R>
+int dev_camera(const rt355_camera_desc* cams, int n_frames, int rank, int n_ranks, DevCamera<R>& out, DevView<R>* views_host) {
+  int cw = 0, chh = 0;
+  if (int rc = camera_dims(cams, cw, chh)) return rc;
+  if (int rc = dev_view<R>(cams, out.view)) return rc;
+  for (int f = 0; f < n_frames && n_frames > 1; ++f) {
+    int w2 = 0, h2 = 0;
+    if (int rc = camera_dims(cams + f, w2, h2)) return rc;
+    if (w2 != cw || h2 != chh) return set_err(RT355_EINVAL, "the cameras of a batch must share hsize and vsize");
+    if (int rc = dev_view<R>(cams + f, views_host[f])) return rc;
+  }
   out.width = cw, out.height = chh;
   out.tiles_x = (out.width + TILE - 1) / TILE, out.tiles_y = (out.height + TILE - 1) / TILE;
   out.n_tiles = out.tiles_x * out.tiles_y;
   out.rank = rank, out.n_ranks = n_ranks;
+  out.n_frames = n_frames;
+  out.tiles_per_frame = (int32_t)((out.n_tiles + n_ranks - 1) / n_ranks);
+  out.views = nullptr;
   return RT355_OK;
 }
 
@@ -459,15 +481,18 @@ int end_frame(rt355_ctx* c, rt355_stats* st) {
   return RT355_OK;
 }
 
+// `n_frames` cameras of one size: one launch chain renders them all (generation 0 holds the frames one after
+// the other), into out_dev frame after frame.
 template <class R>
 int render_impl(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam, int max_depth, int rank, int n_ranks,
-                int out_mode, float* out_dev, rt355_stats* st, bool fixed_workspace = false, bool begin_only = false) {
+                int out_mode, float* out_dev, rt355_stats* st, bool fixed_workspace = false, bool begin_only = false, int n_frames = 1) {
   if (c->pending) return set_err(RT355_EINVAL, "a frame begun on this context has not been ended (rt355_frame_end)");
+  if (n_frames < 1 || n_frames > RT355_MAX_BATCH) return set_err(RT355_EINVAL, "batch: between 1 and RT355_MAX_BATCH frames");
   DevCamera<R> dc;
-  int rc = dev_camera<R>(cam, rank, n_ranks, dc);
+  int rc = dev_camera<R>(cam, n_frames, rank, n_ranks, dc, (DevView<R>*)c->views_host);
   if (rc) return rc;
   const int64_t tpr = tiles_per_rank_of(dc.width, dc.height, n_ranks);
-  const uint64_t n_primary = (uint64_t)tpr * TILE_PIX;
+  const uint64_t n_primary = (uint64_t)tpr * TILE_PIX * (uint64_t)n_frames;
   RayPool<R> pool;
   FrameCtl* ctl = nullptr;
   if (fixed_workspace) {
@@ -475,6 +500,10 @@ int render_impl(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam
   } else {
     if ((rc = ensure_pool<R>(c, n_primary, s->any_secondary && max_depth > 0, pool))) return rc;
     ctl = (FrameCtl*)c->ctl.p;
+  }
+  if (n_frames > 1) {  // the staging buffer is free: the context's previous chain was waited for in end_frame
+    HIP_TRY(hipMemcpyAsync(c->views_dev, c->views_host, (size_t)n_frames * sizeof(DevView<R>), hipMemcpyHostToDevice, c->stream));
+    dc.views = (const DevView<R>*)c->views_dev;
   }
   auto t0 = std::chrono::steady_clock::now();
   LaunchLog log;
@@ -485,7 +514,7 @@ int render_impl(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
   c->pending = true, c->pending_log = log, c->pending_t0 = t0;
-  c->pending_primary_flops = F_PRIMARY * (double)dc.width * dc.height / n_ranks;
+  c->pending_primary_flops = F_PRIMARY * (double)dc.width * dc.height / n_ranks * n_frames;
   return begin_only ? RT355_OK : end_frame(c, st);
 }
 
@@ -619,17 +648,19 @@ int check_ctx(rt355_ctx* c) {
   return RT355_OK;
 }
 
+// n_frames > 1: every rank's buffer holds the tiles of n_frames frames, frame after frame (the layout
+// rt355_render_tiles_batch_begin writes); out_dev receives the frames one canvas after the other.
 template <class T>
-int untile_impl(rt355_ctx* c, const rt355_camera_desc* cam, int n_ranks, const T* gathered_dev, T* out_dev) {
+int untile_impl(rt355_ctx* c, const rt355_camera_desc* cam, int n_ranks, int n_frames, const T* gathered_dev, T* out_dev) {
   int rc = check_ctx(c);
   if (rc) return rc;
-  if (!cam || !gathered_dev || !out_dev || n_ranks < 1) return set_err(RT355_EINVAL, "bad argument");
+  if (!cam || !gathered_dev || !out_dev || n_ranks < 1 || n_frames < 1 || n_frames > RT355_MAX_BATCH) return set_err(RT355_EINVAL, "bad argument");
   int w = 0, h = 0;
   if ((rc = camera_dims(cam, w, h))) return rc;
   const int tiles_x = (w + TILE - 1) / TILE, tiles_y = (h + TILE - 1) / TILE;
-  const long long total = (long long)w * h;
+  const long long total = (long long)w * h * n_frames;
   hipLaunchKernelGGL((k_untile<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, gathered_dev, out_dev, w, h, tiles_x,
-                     tiles_x * tiles_y, n_ranks, (long long)tiles_per_rank_of(w, h, n_ranks));
+                     tiles_x * tiles_y, n_ranks, (long long)tiles_per_rank_of(w, h, n_ranks), n_frames);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
   return RT355_OK;
@@ -666,8 +697,10 @@ int rt355_ctx_create_ex(rt355_ctx** out, int device_id, int real_bits, int flags
   // launches go to one stream of default priority, so that the frames share the device evenly and each context
   // occupies one hardware queue instead of two (measured: three such frames in flight give the best rate).
   if (flags & RT355_CTX_ONE_STREAM) prio_least = prio_greatest = 0, c->use_side = 0;
-  bool ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
-            hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_least) == hipSuccess;
+  bool ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess;
+  // no side stream for a one-stream context: streams are spread over a handful of hardware queues, and two
+  // chains that land on the same queue run one after the other
+  if (c->use_side) ok = ok && hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_least) == hipSuccess;
   for (int i = 0; i <= RT355_MAX_LAUNCH && ok; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
   for (int i = 0; i < RT355_MAX_GEN && ok; ++i) ok = hipEventCreateWithFlags(&c->ev_traced[i], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming) == hipSuccess;
@@ -679,6 +712,11 @@ int rt355_ctx_create_ex(rt355_ctx** out, int device_id, int real_bits, int flags
     c->ctl_host = nullptr;
     rt355_ctx_destroy(c);
     return set_err(RT355_ENOMEM, "pinned host allocation failed");
+  }
+  const size_t views_bytes = (size_t)RT355_MAX_BATCH * sizeof(DevView<double>);
+  if (hipHostMalloc(&c->views_host, views_bytes, hipHostMallocDefault) != hipSuccess || hipMalloc(&c->views_dev, views_bytes) != hipSuccess) {
+    rt355_ctx_destroy(c);
+    return set_err(RT355_ENOMEM, "allocation of the batch view table failed");
   }
   if (int rc = scratch_address(device_id, &c->fixed_scratch)) {  // the device is current here
     rt355_ctx_destroy(c);
@@ -708,6 +746,8 @@ void rt355_ctx_destroy(rt355_ctx* c) {
   if (c->side) (void)hipStreamDestroy(c->side);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->ctl_host) (void)hipHostFree(c->ctl_host);
+  if (c->views_host) (void)hipHostFree(c->views_host);
+  if (c->views_dev) (void)hipFree(c->views_dev);
   delete c;
 }
 
@@ -805,6 +845,28 @@ int rt355_render_device_begin(rt355_ctx* c, const rt355_scene* s, const rt355_ca
                             : render_impl<double>(c, s, cam, max_depth, 0, 1, OUT_ROWMAJOR, rgb_out_dev, nullptr, false, true);
 }
 
+static int check_batch_args(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cams, int n_frames, int max_depth) {
+  if (n_frames < 1 || n_frames > RT355_MAX_BATCH) return set_err(RT355_EINVAL, "batch: between 1 and RT355_MAX_BATCH frames");
+  return check_render_args(c, s, cams, max_depth);
+}
+
+int rt355_render_tiles_batch_begin(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cams, int n_frames, int max_depth, int rank, int n_ranks,
+                                   float* tiles_out_dev) {
+  int rc = check_batch_args(c, s, cams, n_frames, max_depth);
+  if (rc) return rc;
+  if (n_ranks < 1 || rank < 0 || rank >= n_ranks || !tiles_out_dev) return set_err(RT355_EINVAL, "bad rank / n_ranks / output");
+  return c->real_bits == 32 ? render_impl<float>(c, s, cams, max_depth, rank, n_ranks, OUT_TILES, tiles_out_dev, nullptr, false, true, n_frames)
+                            : render_impl<double>(c, s, cams, max_depth, rank, n_ranks, OUT_TILES, tiles_out_dev, nullptr, false, true, n_frames);
+}
+
+int rt355_render_device_batch_begin(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cams, int n_frames, int max_depth, float* rgb_out_dev) {
+  int rc = check_batch_args(c, s, cams, n_frames, max_depth);
+  if (rc) return rc;
+  if (!rgb_out_dev) return set_err(RT355_EINVAL, "null output");
+  return c->real_bits == 32 ? render_impl<float>(c, s, cams, max_depth, 0, 1, OUT_ROWMAJOR, rgb_out_dev, nullptr, false, true, n_frames)
+                            : render_impl<double>(c, s, cams, max_depth, 0, 1, OUT_ROWMAJOR, rgb_out_dev, nullptr, false, true, n_frames);
+}
+
 int rt355_frame_end(rt355_ctx* c, rt355_stats* stats) {
   int rc = check_ctx(c);
   if (rc) return rc;
@@ -884,10 +946,16 @@ int rt355_render_tiles(rt355_ctx* c, const rt355_scene* s, const rt355_camera_de
 }
 
 int rt355_untile(rt355_ctx* c, const rt355_camera_desc* cam, int n_ranks, const float* gathered_dev, float* rgb_out_dev) {
-  return untile_impl<float>(c, cam, n_ranks, gathered_dev, rgb_out_dev);
+  return untile_impl<float>(c, cam, n_ranks, 1, gathered_dev, rgb_out_dev);
 }
 int rt355_untile_u8(rt355_ctx* c, const rt355_camera_desc* cam, int n_ranks, const uint8_t* gathered_dev, uint8_t* rgb_out_dev) {
-  return untile_impl<uint8_t>(c, cam, n_ranks, gathered_dev, rgb_out_dev);
+  return untile_impl<uint8_t>(c, cam, n_ranks, 1, gathered_dev, rgb_out_dev);
+}
+int rt355_untile_batch(rt355_ctx* c, const rt355_camera_desc* cam, int n_ranks, int n_frames, const float* gathered_dev, float* rgb_out_dev) {
+  return untile_impl<float>(c, cam, n_ranks, n_frames, gathered_dev, rgb_out_dev);
+}
+int rt355_untile_batch_u8(rt355_ctx* c, const rt355_camera_desc* cam, int n_ranks, int n_frames, const uint8_t* gathered_dev, uint8_t* rgb_out_dev) {
+  return untile_impl<uint8_t>(c, cam, n_ranks, n_frames, gathered_dev, rgb_out_dev);
 }
 
 int rt355_color_at(rt355_ctx* c, const rt355_scene* s, const float* rays, size_t n, int max_depth, float* rgb_out, rt355_stats* stats) {

@@ -20,6 +20,13 @@ constexpr int TILE_PIX = TILE * TILE;
 constexpr int STACK_DEPTH = 64;      // traversal stack entries; the builder rejects trees that could need more
 constexpr int LDS_STACK = 24;        // of which this many live in LDS (one column per lane); the rest in scratch
 constexpr int BLOCK = 256;           // threads per block of the traversal kernels
+// Waves per SIMD the per-lane kernels are compiled for (the register budget is 512 / this per lane).
+#ifndef RT355_WPS_LANE
+#define RT355_WPS_LANE 3
+#endif
+#ifndef RT355_WPS_SPAWN
+#define RT355_WPS_SPAWN 3
+#endif
 constexpr uint32_t LEAF_FIRST_MASK = 0x1FFFFFFu;  // leaf reference ~c: first | tri-only flag << 25 | count << 26
 constexpr uint32_t LEAF_TRI_BIT = 1u << 25;       // every prim of the leaf is a triangle with identity transform
 constexpr int MAX_TREE_DEPTH = 40;   // of the binary tree the builder collapses; a 4-wide node pushes up to 3 entries
@@ -95,12 +102,24 @@ struct DevScene {
   R light_pos[3], light_int[3];
 };
 
+// What differs between the frames of one batch: the view.  (Image size, tiling and rank are shared.)
 template <class R>
-struct DevCamera {
+struct DevView {
   R inv[12];  // rows 0..2 of the inverse camera transformation
   R half_width, half_height, pixel_size;
+  R pad;
+};
+
+// Camera of a launch chain.  A chain may carry several frames of the same size (a batch): generation 0 then
+// holds the frames one after the other, `tiles_per_frame` tiles of this rank each, frame f seen through
+// views[f].  With n_frames == 1 the view is `view` and `views` is not read.
+template <class R>
+struct DevCamera {
+  DevView<R> view;
   int32_t width, height, tiles_x, tiles_y, n_tiles;
   int32_t rank, n_ranks;
+  int32_t n_frames, tiles_per_frame;
+  const DevView<R>* views;
 };
 
 // Per-frame ray pool, structure of arrays indexed by ray id.  Generation g occupies the id range

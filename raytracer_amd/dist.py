@@ -84,35 +84,46 @@ def untile(device, camera, world_size, gathered, out_tensor):
 class FrameLoop:
     """One rank's side of a frame loop: render this rank's tiles, gather them to rank 0, un-tile there.
 
-    `in_flight` frames are kept in flight on the GPU.  A frame is a chain of dependent launches, each ending on
-    its slowest wave, so one frame alone leaves much of the device idle; with K > 1 every frame runs in a
-    context of its own (one stream each, rt355_ctx_create_ex RT355_CTX_ONE_STREAM; the uploaded scene is
-    shared) and `step` hands back the canvas of the frame begun K steps earlier.  `flush` completes what is
-    still in flight.  With K = 1 a step renders and returns its own frame.
+    A frame is a chain of dependent launches, each ending on its slowest wave, so one frame alone -- and all the
+    more the few tiles one rank of many renders of it -- leaves much of the device idle.  Two things fill it:
+
+    `batch` frames share ONE launch chain (rt355_render_tiles_batch_begin): `step` collects cameras and launches
+    when it holds `batch` of them; the rays of all the frames are traced together, their tiles are gathered in
+    one collective and un-tiled in one launch.
+
+    `in_flight` chains are kept in flight, each in a context of its own (one stream each, rt355_ctx_create_ex
+    RT355_CTX_ONE_STREAM; the uploaded scene is shared).
+
+    `step` hands back finished canvases in the order the frames were begun, one per call, or None while the
+    pipeline fills; `flush` completes what is still collected or in flight.  With batch = in_flight = 1 a step
+    renders and returns its own frame.
 
     Every slot owns its tile buffer.  With the nccl backend `dist.gather` only enqueues the send on a
     communication stream and returns, while the library renders on streams of its own: a rank other than 0 that
-    rendered a later frame into the same buffer could overwrite tiles that are still being sent.  Each slot
+    rendered later frames into the same buffer could overwrite tiles that are still being sent.  Each slot
     therefore remembers an event recorded behind its last send and does not render before that event has
     passed (in steady state it passed long ago).  Rank 0 synchronises with the gather before it un-tiles.
 
-    `render(camera, out_tensor, stats)` writes this rank's tiles of the frame into the tensor it is given; the
+    `render(camera, out_tensor, stats)` writes this rank's tiles of one frame into the tensor it is given; the
     default calls the library (CUDA tensors); tests pass their own to run the same loop on CPU tensors over
     gloo.  `as_u8`: the tiles go through Color::to_u8 on the device before the gather (a quarter of the bytes)
     and the canvas is uint8, the body of a binary PPM.
     """
 
     def __init__(self, scene, device, width, height, rank, world_size, max_depth=5, group=None, tensor_device="cuda",
-                 render=None, as_u8=False, in_flight=1):
+                 render=None, as_u8=False, in_flight=1, batch=1):
+        import collections
         import torch
         self.scene, self.device, self.rank, self.world_size, self.group = scene, device, rank, world_size, group
         self.width, self.height, self.max_depth, self.as_u8 = width, height, max_depth, as_u8
         self.cuda = str(tensor_device).startswith("cuda")
         self.K = K = max(1, int(in_flight))
+        self.B = B = max(1, min(int(batch), _abi.MAX_BATCH))
         self._custom = render
-        n = tiles_per_rank(width, height, world_size) * TILE * TILE * 3
-        out_dtype = torch.uint8 if as_u8 else torch.float32
-        # with one rank and a float canvas the frame is written row-major in place: nothing to gather or un-tile
+        self.n = n = tiles_per_rank(width, height, world_size) * TILE * TILE * 3  # floats of one frame's tiles on one rank
+        self.out_dtype = out_dtype = torch.uint8 if as_u8 else torch.float32
+        self.tensor_device = tensor_device
+        # with one rank and a float canvas the frames are written row-major in place: nothing to gather or un-tile
         self.direct = self.cuda and render is None and world_size == 1 and not as_u8
         if render is None and K > 1:
             from .host import Device
@@ -120,15 +131,22 @@ class FrameLoop:
             self._own_ctxs = True
         else:
             self.ctxs, self._own_ctxs = [device] * K, False
-        self.tiles = [None if self.direct else torch.empty(n, dtype=torch.float32, device=tensor_device) for _ in range(K)]
-        self.send = [torch.empty(n, dtype=out_dtype, device=tensor_device) for _ in range(K)] if as_u8 else self.tiles
+        self.tiles = [None if self.direct else torch.empty(B * n, dtype=torch.float32, device=tensor_device) for _ in range(K)]
+        self.send = [torch.empty(B * n, dtype=out_dtype, device=tensor_device) for _ in range(K)] if as_u8 else self.tiles
         self.sent = [None] * K      # event behind the last send of each slot's buffer
-        self.pending = [None] * K   # camera of the frame in flight in each slot
-        self.gathered = torch.empty((world_size, n), dtype=out_dtype, device=tensor_device) if (rank == 0 and not self.direct) else None
-        n_canvas = K if self.direct else 1
-        self.canvases = [torch.empty((height, width, 3), dtype=out_dtype, device=tensor_device) for _ in range(n_canvas)] if rank == 0 else []
-        self.canvas = self.canvases[0] if rank == 0 else None
+        self.pending = [None] * K   # cameras of the chain in flight in each slot
+        self.where = [0] * K        # direct mode: which canvas set the slot's chain writes
+        self.gathered = torch.empty((world_size, B * n), dtype=out_dtype, device=tensor_device) if (rank == 0 and not self.direct) else None
+        # direct mode renders into the canvases themselves: one set more than chains in flight, so the set whose
+        # canvases are being handed out is never the one the next chain writes
+        n_sets = K + 1 if self.direct else 1
+        self.canvases = [torch.empty((B, height, width, 3), dtype=out_dtype, device=tensor_device) for _ in range(n_sets)] if rank == 0 else []
+        self.canvas = self.canvases[0][0] if rank == 0 else None
+        self.cams = []              # cameras collected for the next chain
+        self.ready = collections.deque()
+        self.launches = 0
         self.frame = 0
+        self.stats_frames = 0       # how many frames the statistics of the last finished chain cover
 
     def close(self):
         self.flush()
@@ -138,83 +156,112 @@ class FrameLoop:
             self.ctxs, self._own_ctxs = [], False
 
     # -- one slot -------------------------------------------------------------------------------------------
-    def _begin(self, k, camera):
+    def _begin(self, k, cameras):
+        nf = len(cameras)
         if self.sent[k] is not None:
             self.sent[k].synchronize()  # an earlier send read this slot's buffer
             self.sent[k] = None
         if self._custom is not None:
-            self._custom(camera, self.tiles[k], None)
+            for f, camera in enumerate(cameras):
+                self._custom(camera, self.tiles[k][f * self.n:(f + 1) * self.n], None)
         else:
-            ctx, cd = self.ctxs[k], camera.to_desc()
+            ctx = self.ctxs[k]
+            cds = (_abi.CameraDesc * nf)(*[c.to_desc() for c in cameras])
             if self.direct:
-                _abi.check(ctx.lib.rt355_render_device_begin(ctx.handle, self.scene.handle, C.byref(cd), self.max_depth,
-                                                             C.c_void_p(self.canvases[k].data_ptr())))
+                self.where[k] = self.launches % len(self.canvases)
+                _abi.check(ctx.lib.rt355_render_device_batch_begin(ctx.handle, self.scene.handle, cds, nf, self.max_depth,
+                                                                   C.c_void_p(self.canvases[self.where[k]].data_ptr())))
             else:
-                _abi.check(ctx.lib.rt355_render_tiles_begin(ctx.handle, self.scene.handle, C.byref(cd), self.max_depth, self.rank, self.world_size,
-                                                            C.c_void_p(self.tiles[k].data_ptr())))
-        self.pending[k] = camera
+                _abi.check(ctx.lib.rt355_render_tiles_batch_begin(ctx.handle, self.scene.handle, cds, nf, self.max_depth, self.rank, self.world_size,
+                                                                  C.c_void_p(self.tiles[k].data_ptr())))
+        self.launches += 1
+        self.pending[k] = list(cameras)
 
     def _finish(self, k, stats):
+        """Completes the chain of slot k; on rank 0 its canvases join `ready`."""
         import torch
         import torch.distributed as dist
-        camera, ctx = self.pending[k], self.ctxs[k]
+        cameras, ctx = self.pending[k], self.ctxs[k]
+        nf, n = len(cameras), self.n
         self.pending[k] = None
         if self._custom is None:
             _abi.check(ctx.lib.rt355_frame_end(ctx.handle, C.byref(stats) if stats is not None else None))  # the tiles are complete
+        self.stats_frames = nf
         if self.direct:
-            self.canvas = self.canvases[k]
-            return self.canvas
+            self.ready.extend(self.canvases[self.where[k]][f] for f in range(nf))
+            return
+        tiles, send = self.tiles[k][: nf * n], self.send[k][: nf * n]
         if self.as_u8:
             if self.cuda:
-                _abi.check(ctx.lib.rt355_to_u8_device(ctx.handle, C.c_void_p(self.tiles[k].data_ptr()), self.tiles[k].numel(),
-                                                      C.c_void_p(self.send[k].data_ptr())))
+                _abi.check(ctx.lib.rt355_to_u8_device(ctx.handle, C.c_void_p(tiles.data_ptr()), tiles.numel(), C.c_void_p(send.data_ptr())))
             else:
                 from .host import Color
-                self.send[k].copy_(torch.from_numpy(Color.to_u8(self.tiles[k].numpy())))
+                send.copy_(torch.from_numpy(Color.to_u8(tiles.numpy())))
+        gathered = None
+        if self.rank == 0:  # a chain shorter than `batch` (the last one) is gathered into a buffer of its own size
+            gathered = self.gathered if nf == self.B else torch.empty((self.world_size, nf * n), dtype=self.out_dtype, device=self.tensor_device)
         if self.world_size > 1:
-            dist.gather(self.send[k], list(self.gathered.unbind(0)) if self.rank == 0 else None, dst=0, group=self.group)
+            dist.gather(send, list(gathered.unbind(0)) if self.rank == 0 else None, dst=0, group=self.group)
             if self.cuda and self.rank != 0:
                 self.sent[k] = torch.cuda.Event()
                 self.sent[k].record()  # torch's current stream, which the nccl work was ordered on
         elif self.rank == 0:
-            self.gathered[0].copy_(self.send[k])
+            gathered[0].copy_(send)
         if self.rank != 0:
-            return None
+            return
+        canvases = self.canvases[0]
         if self.cuda:
-            fn = ctx.lib.rt355_untile_u8 if self.as_u8 else ctx.lib.rt355_untile
+            fn = ctx.lib.rt355_untile_batch_u8 if self.as_u8 else ctx.lib.rt355_untile_batch
             torch.cuda.current_stream().synchronize()  # the gather has landed before the library's stream reads it
-            cd = camera.to_desc()
-            _abi.check(fn(ctx.handle, C.byref(cd), self.world_size, C.c_void_p(self.gathered.data_ptr()), C.c_void_p(self.canvas.data_ptr())))
+            cd = cameras[0].to_desc()
+            _abi.check(fn(ctx.handle, C.byref(cd), self.world_size, nf, C.c_void_p(gathered.data_ptr()), C.c_void_p(canvases.data_ptr())))
         else:
-            g = self.gathered.numpy()
-            self.canvas.copy_(torch.from_numpy(untile_host(g, self.width, self.height, self.world_size, dtype=g.dtype)))
-        return self.canvas
+            g = gathered.numpy()
+            for f in range(nf):
+                canvases[f].copy_(torch.from_numpy(untile_host(g[:, f * n:(f + 1) * n], self.width, self.height, self.world_size, dtype=g.dtype)))
+        self.ready.extend(canvases[f] for f in range(nf))
+
+    def _launch(self, stats):
+        k = self.launches % self.K
+        if self.pending[k] is not None:
+            self._finish(k, stats)
+        cameras, self.cams = self.cams, []
+        self._begin(k, cameras)
+        if self.K == 1 and self.B == 1:
+            self._finish(k, stats)
 
     # -- the loop -------------------------------------------------------------------------------------------
     def step(self, camera, stats=None):
-        """Begins the frame of `camera`.  Returns, on rank 0, the canvas of the frame that completed in this step
-        (valid until the next step): this frame with in_flight = 1, the frame begun in_flight steps ago otherwise
-        (None while the pipeline fills); None on other ranks."""
-        k = self.frame % self.K
+        """Adds the frame of `camera`.  Returns, on rank 0, the next finished canvas in the order the frames were
+        begun (valid until the next step), or None while the pipeline fills; always None on other ranks.  With
+        batch = in_flight = 1 that is this very frame."""
         self.frame += 1
-        done = None
-        if self.K == 1:
-            self._begin(k, camera)
-            return self._finish(k, stats)
-        if self.pending[k] is not None:
-            done = self._finish(k, stats)
-        self._begin(k, camera)
-        return done
+        self.cams.append(camera)
+        if len(self.cams) == self.B:
+            self._launch(stats)
+        if self.ready:
+            self.canvas = self.ready.popleft()
+            return self.canvas
+        return None
 
     def flush(self, stats=None):
-        """Completes the frames still in flight, oldest first; returns their canvases (copies) on rank 0."""
+        """Launches the cameras still collected and completes every chain in flight, oldest first; returns, on
+        rank 0, the canvases not yet handed out (copies)."""
         out = []
+
+        def drain():  # chains share the canvas set they are un-tiled into: copy before the next one lands
+            out.extend(c.clone() for c in self.ready)
+            self.ready.clear()
+
+        if self.cams:
+            drain()
+            self._launch(stats)
         for j in range(self.K):
-            k = (self.frame + j) % self.K
+            k = (self.launches + j) % self.K
             if self.pending[k] is not None:
-                c = self._finish(k, stats)
-                if c is not None:
-                    out.append(c.clone())
+                drain()
+                self._finish(k, stats)
+        drain()
         return out
 
 

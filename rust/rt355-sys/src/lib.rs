@@ -14,6 +14,7 @@ pub const RT355_MAX_GEN: usize = 8;
 pub const RT355_MAX_LAUNCH: usize = 48;
 pub const RT355_NOALLOC_BYTES: usize = 64 << 20;
 pub const RT355_CTX_ONE_STREAM: c_int = 1;
+pub const RT355_MAX_BATCH: usize = 64;
 
 // enum rt355_kind: position in `enum Shape` (src/shape.rs:11-20)
 pub const RT355_SPHERE: i32 = 0;
@@ -136,11 +137,20 @@ extern "C" {
     pub fn rt355_render_device_begin(ctx: *mut rt355_ctx, scene: *const rt355_scene, cam: *const rt355_camera_desc,
                                      max_depth: c_int, rgb_out_dev: *mut f32) -> c_int;
     pub fn rt355_frame_end(ctx: *mut rt355_ctx, stats: *mut rt355_stats) -> c_int;
+    pub fn rt355_render_tiles_batch_begin(ctx: *mut rt355_ctx, scene: *const rt355_scene, cams: *const rt355_camera_desc,
+                                          n_frames: c_int, max_depth: c_int, rank: c_int, n_ranks: c_int,
+                                          tiles_out_dev: *mut f32) -> c_int;
+    pub fn rt355_render_device_batch_begin(ctx: *mut rt355_ctx, scene: *const rt355_scene, cams: *const rt355_camera_desc,
+                                           n_frames: c_int, max_depth: c_int, rgb_out_dev: *mut f32) -> c_int;
     pub fn rt355_tiles_per_rank(cam: *const rt355_camera_desc, n_ranks: c_int) -> i64;
     pub fn rt355_untile(ctx: *mut rt355_ctx, cam: *const rt355_camera_desc, n_ranks: c_int,
                         gathered_dev: *const f32, rgb_out_dev: *mut f32) -> c_int;
     pub fn rt355_untile_u8(ctx: *mut rt355_ctx, cam: *const rt355_camera_desc, n_ranks: c_int,
                            gathered_dev: *const u8, rgb_out_dev: *mut u8) -> c_int;
+    pub fn rt355_untile_batch(ctx: *mut rt355_ctx, cam: *const rt355_camera_desc, n_ranks: c_int, n_frames: c_int,
+                              gathered_dev: *const f32, rgb_out_dev: *mut f32) -> c_int;
+    pub fn rt355_untile_batch_u8(ctx: *mut rt355_ctx, cam: *const rt355_camera_desc, n_ranks: c_int, n_frames: c_int,
+                                 gathered_dev: *const u8, rgb_out_dev: *mut u8) -> c_int;
     pub fn rt355_multi_create(out: *mut *mut rt355_multi, device_ids: *const c_int, n_devices: c_int,
                               real_bits: c_int) -> c_int;
     pub fn rt355_multi_destroy(multi: *mut rt355_multi);

@@ -15,8 +15,20 @@ ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--frames", type=int, default=3)
 ap.add_argument("--real", type=int, default=64)
+ap.add_argument("--keep", default="", help="diagnostic: keep only these shapes of the scene: floor, sphere, mesh (comma list); 'matte' also makes every material non-reflective and opaque")
 a = ap.parse_args()
 world, cam = scenes.CONFIGS[a.scene](a.width, a.height)
+if a.keep:
+    keep = set(a.keep.split(","))
+    from raytracer_amd import _abi
+    kinds = {"floor": (_abi.PLANE,), "sphere": (_abi.SPHERE,), "mesh": (_abi.TRIANGLE, _abi.SMOOTH_TRIANGLE)}
+    wanted = {k for name in keep if name in kinds for k in kinds[name]}
+    world.shapes = [s for s in world.shapes if s.kind in wanted]
+    if "matte" in keep:
+        for s in world.shapes:
+            s.material.reflective = 0.0
+            s.material.transparency = 0.0
+    print("shapes kept:", len(world.shapes))
 dev = Device.get(0, a.real)
 scene = dev.upload(world)
 out = torch.empty(rd.tiles_per_rank(a.width, a.height, 1) * 1024 * 3, dtype=torch.float32, device="cuda")

@@ -608,11 +608,11 @@ def test_frame_loop_on_one_rank(dev):
         for _ in range(3):
             got8 = loop8.step(cam).cpu().numpy()
             assert got8.dtype == np.uint8 and np.array_equal(got8, Color.to_u8(want))
-        # frames in flight: different cameras back to back, each canvas comes back K steps later, in order
+        # chains in flight, several frames per chain: different cameras back to back, the canvases come back in order
         cams = [scenes.glass(100, 70)[1]] + [Camera(100, 70, math.pi / 3, mx.view_transformation(mx.point(0.3 * k, 1.5, -5.0), mx.point(0, 1, 0), mx.vector(0, 1, 0))) for k in range(1, 7)]
         wants = [scene.render(c, 5).pixels for c in cams]
-        for as_u8 in (False, True):
-            loop3 = rd.FrameLoop(scene, dev, 100, 70, 0, 1, as_u8=as_u8, in_flight=3)
+        for as_u8, in_flight, batch in ((False, 3, 1), (True, 3, 1), (False, 1, 4), (True, 2, 3), (False, 2, 2)):
+            loop3 = rd.FrameLoop(scene, dev, 100, 70, 0, 1, as_u8=as_u8, in_flight=in_flight, batch=batch)
             st = Stats()
             outs = []
             for c in cams:
@@ -624,6 +624,58 @@ def test_frame_loop_on_one_rank(dev):
             assert len(outs) == len(cams) and int(st.total_radiance) > 7000
             for o, wnt in zip(outs, wants):
                 assert np.array_equal(o, Color.to_u8(wnt) if as_u8 else wnt)
+    finally:
+        scene.close()
+
+
+@pytest.mark.parametrize("real_bits", [64, 32])
+def test_batch_of_frames_in_one_launch_chain(real_bits):
+    """rt355_render_tiles_batch_begin / rt355_untile_batch: several cameras of one size rendered by ONE launch
+    chain, as rank r of 3.  Every frame's tiles must be bit-identical to rt355_render_tiles of that camera
+    alone, the statistics must be the sums, and the gathered rank buffers must un-tile to the frames'
+    canvases.  Cameras of different sizes are refused."""
+    import ctypes as C
+    import torch
+    from raytracer_amd import _abi
+    from raytracer_amd import dist as rd
+    w, h, n_ranks = 150, 100, 3
+    world, cam0 = scenes.glass(w, h)
+    cams = [cam0] + [Camera(w, h, math.pi / (3 + 0.2 * k), mx.view_transformation(mx.point(0.4 * k, 1.5 + 0.1 * k, -5.0), mx.point(0, 1, 0), mx.vector(0, 1, 0))) for k in range(1, 5)]
+    dev = Device.get(0, real_bits)
+    scene = dev.upload(world)
+    lib = dev.lib
+    try:
+        n = rd.tiles_per_rank(w, h, n_ranks) * 1024 * 3
+        cds = (_abi.CameraDesc * len(cams))(*[c.to_desc() for c in cams])
+        gathered = torch.empty((n_ranks, len(cams) * n), dtype=torch.float32, device="cuda")
+        for rank in range(n_ranks):
+            singles, rays = [], 0
+            for c in cams:
+                t = torch.empty(n, dtype=torch.float32, device="cuda")
+                st = Stats()
+                rd.render_tiles(scene, c, 5, rank, n_ranks, t, st)
+                singles.append(t)
+                rays += int(st.total_radiance) + int(st.total_shadow)
+            st = Stats()
+            _abi.check(lib.rt355_render_tiles_batch_begin(dev.handle, scene.handle, cds, len(cams), 5, rank, n_ranks, C.c_void_p(gathered[rank].data_ptr())))
+            _abi.check(lib.rt355_frame_end(dev.handle, C.byref(st)))
+            assert int(st.total_radiance) + int(st.total_shadow) == rays
+            assert torch.equal(gathered[rank], torch.cat(singles))
+        canvases = torch.empty((len(cams), h, w, 3), dtype=torch.float32, device="cuda")
+        _abi.check(lib.rt355_untile_batch(dev.handle, C.byref(cds[0]), n_ranks, len(cams), C.c_void_p(gathered.data_ptr()), C.c_void_p(canvases.data_ptr())))
+        direct = torch.empty_like(canvases)
+        _abi.check(lib.rt355_render_device_batch_begin(dev.handle, scene.handle, cds, len(cams), 5, C.c_void_p(direct.data_ptr())))
+        _abi.check(lib.rt355_frame_end(dev.handle, None))
+        for f, c in enumerate(cams):
+            want = scene.render(c, 5).pixels
+            assert np.array_equal(canvases[f].cpu().numpy(), want), f
+            assert np.array_equal(direct[f].cpu().numpy(), want), f
+        # one size per chain
+        other = Camera(w + 32, h, math.pi / 3, cam0.transform)
+        bad = (_abi.CameraDesc * 2)(cam0.to_desc(), other.to_desc())
+        rc = lib.rt355_render_device_batch_begin(dev.handle, scene.handle, bad, 2, 5, C.c_void_p(direct.data_ptr()))
+        assert rc == -1 and b"share" in lib.rt355_last_error()  # RT355_EINVAL
+        assert lib.rt355_render_device_batch_begin(dev.handle, scene.handle, cds, _abi.MAX_BATCH + 1, 5, C.c_void_p(direct.data_ptr())) == -1
     finally:
         scene.close()
 

@@ -469,7 +469,7 @@ def test_gather_canvas_over_gloo(world_size):
     assert got.shape == (h, w, 3) and (got == want).all()
 
 
-def _frame_loop_worker(rank, world_size, port, w, h, as_u8, in_flight, q):
+def _frame_loop_worker(rank, world_size, port, w, h, as_u8, in_flight, batch, n_frames, q):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -483,16 +483,16 @@ def _frame_loop_worker(rank, world_size, port, w, h, as_u8, in_flight, q):
             v = np.where(idx >= 0, ((idx % 251) + frame_no) / 255.0, -7.0).astype(np.float32)
             out_tensor.copy_(torch.from_numpy(np.repeat(v[..., None], 3, axis=-1).reshape(-1)))
 
-        loop = rd.FrameLoop(None, None, w, h, rank, world_size, tensor_device="cpu", render=fake_render, as_u8=as_u8, in_flight=in_flight)
+        loop = rd.FrameLoop(None, None, w, h, rank, world_size, tensor_device="cpu", render=fake_render, as_u8=as_u8, in_flight=in_flight, batch=batch)
         frames = []
-        for f in range(5):  # different frames back to back: every slot's tile buffer gets reused
+        for f in range(n_frames):  # different frames back to back: every slot's tile buffer gets reused
             out = loop.step(f)
             if rank == 0 and out is not None:
                 frames.append(out.numpy().copy())
             elif rank != 0:
                 assert out is None
-            if in_flight > 1:
-                assert (out is None) == (f < in_flight or rank != 0)  # a frame comes back in_flight steps after it began
+            if in_flight > 1 or batch > 1:  # the first canvas comes back when the first chain's slot is taken again
+                assert (out is None) == (f < (in_flight + 1) * batch - 1 or rank != 0)
         rest = loop.flush()
         if rank == 0:
             frames += [c.numpy() for c in rest]
@@ -503,11 +503,12 @@ def _frame_loop_worker(rank, world_size, port, w, h, as_u8, in_flight, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("as_u8,in_flight", [(False, 1), (True, 1), (False, 3), (True, 2)])
-def test_frame_loop_over_gloo(as_u8, in_flight):
+@pytest.mark.parametrize("as_u8,in_flight,batch", [(False, 1, 1), (True, 1, 1), (False, 3, 1), (True, 2, 1), (False, 1, 2), (False, 2, 3), (True, 3, 2)])
+def test_frame_loop_over_gloo(as_u8, in_flight, batch):
     """The loop bench.py times for N > 1 (FrameLoop.step: render tiles, gather, un-tile), on CPU tensors over
     gloo with a stand-in renderer: consecutive DIFFERENT frames must each arrive intact on rank 0, as float
-    tiles and as tiles taken through Color::to_u8 before the gather."""
+    tiles and as tiles taken through Color::to_u8 before the gather -- one frame per chain or `batch` frames per
+    chain (the last chain then holds fewer), one chain or several in flight."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
@@ -517,7 +518,8 @@ def test_frame_loop_over_gloo(as_u8, in_flight):
     w, h, world_size = 100, 70, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_frame_loop_worker, args=(r, world_size, port, w, h, as_u8, in_flight, q)) for r in range(world_size)]
+    n_frames = 5 if batch == 1 else 11
+    procs = [ctx.Process(target=_frame_loop_worker, args=(r, world_size, port, w, h, as_u8, in_flight, batch, n_frames, q)) for r in range(world_size)]
     for p in procs:
         p.start()
     frames = q.get(timeout=120)
@@ -525,7 +527,7 @@ def test_frame_loop_over_gloo(as_u8, in_flight):
         p.join(60)
         assert p.exitcode == 0
     base = (np.arange(w * h) % 251).reshape(h, w, 1)
-    assert len(frames) == 5  # every frame arrives, in order, whatever the pipeline depth
+    assert len(frames) == n_frames  # every frame arrives, in order, whatever the pipeline depth
     for f, got in enumerate(frames):
         if as_u8:
             want = np.repeat(np.clip(base + f, 0, 255), 3, axis=2).astype(np.uint8)
