@@ -353,69 +353,6 @@ RT_FN void traverse(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work& wk,
   int spill[STACK_DEPTH - LDS_STACK];
   int sp = 0;
   int cur = 0;
-#ifdef RT355_EXP_WW
-  for (;;) {
-    // node phase: every lane walks down until it stands on a leaf, so the leaf phase below runs with as many
-    // lanes as possible (a wave pays for a phase whenever one of its lanes is in it)
-    while (cur >= 0) {
-      const BvhNode4 N = sc.nodes[cur];
-      float tlo, thi;
-      slab_interval(vis.tmin(), vis.tmax(), tlo, thi);
-      float k0, k1, k2, k3;
-      if (!slab_test(sr, N.box[0][0], N.box[0][1], N.box[0][2], N.box[0][3], N.box[0][4], N.box[0][5], tlo, thi, k0)) k0 = INFINITY;
-      if (!slab_test(sr, N.box[1][0], N.box[1][1], N.box[1][2], N.box[1][3], N.box[1][4], N.box[1][5], tlo, thi, k1)) k1 = INFINITY;
-      if (!slab_test(sr, N.box[2][0], N.box[2][1], N.box[2][2], N.box[2][3], N.box[2][4], N.box[2][5], tlo, thi, k2)) k2 = INFINITY;
-      if (!slab_test(sr, N.box[3][0], N.box[3][1], N.box[3][2], N.box[3][3], N.box[3][4], N.box[3][5], tlo, thi, k3)) k3 = INFINITY;
-      int c0 = N.c[0], c1 = N.c[1], c2 = N.c[2], c3 = N.c[3];
-      if constexpr (COUNT) wk.box += (c0 != -1) + (c1 != -1) + (c2 != -1) + (c3 != -1);
-      auto order = [](float& ka, int& ca, float& kb, int& cb) {
-        const bool sw = kb < ka;
-        const float kt = sw ? kb : ka, ku = sw ? ka : kb;
-        const int ct = sw ? cb : ca, cu = sw ? ca : cb;
-        ka = kt, kb = ku, ca = ct, cb = cu;
-      };
-      order(k0, c0, k1, c1), order(k2, c2, k3, c3), order(k0, c0, k2, c2), order(k1, c1, k3, c3), order(k1, c1, k2, c2);
-      auto push = [&](int child) {
-        if (sp < LDS_STACK) lds[sp * BLOCK] = child; else spill[sp - LDS_STACK] = child;
-        ++sp;
-      };
-      if (k3 < INFINITY) push(c3);
-      if (k2 < INFINITY) push(c2);
-      if (k1 < INFINITY) push(c1);
-      if (k0 < INFINITY) { cur = c0; continue; }
-      if (sp == 0) return;
-      --sp;
-      cur = sp < LDS_STACK ? lds[sp * BLOCK] : spill[sp - LDS_STACK];
-    }
-    {
-      const uint32_t leaf = (uint32_t)~cur;
-      const int first = (int)(leaf & LEAF_FIRST_MASK), count = (int)(leaf >> 26);
-      if (leaf & LEAF_TRI_BIT) {
-        DevTri T[LEAF_MAX];
-#pragma unroll
-        for (int k = 0; k < LEAF_MAX; ++k) T[k] = sc.tri[first + (k < count ? k : 0)];
-#pragma unroll
-        for (int k = 0; k < LEAF_MAX; ++k)
-          if (k < count) {
-            if constexpr (COUNT) wk.prim[T[k].flags & PF_KIND_MASK]++;
-            if (vis.tri(first + k, T[k])) return;
-          }
-        for (int k = LEAF_MAX; k < count; ++k) {
-          const DevTri Tk = sc.tri[first + k];
-          if constexpr (COUNT) wk.prim[Tk.flags & PF_KIND_MASK]++;
-          if (vis.tri(first + k, Tk)) return;
-        }
-      } else {
-        for (int k = 0; k < count; ++k)
-          if (vis.prim(first + k)) return;
-      }
-    }
-    if (sp == 0) return;
-    --sp;
-    cur = sp < LDS_STACK ? lds[sp * BLOCK] : spill[sp - LDS_STACK];
-  }
-}
-#else
   for (;;) {
 #ifdef RT355_EXP_STAMPS
     DbgAcc& dacc = wk.dbg;
@@ -484,8 +421,6 @@ RT_FN void traverse(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work& wk,
     cur = sp < LDS_STACK ? lds[sp * BLOCK] : spill[sp - LDS_STACK];
   }
 }
-
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // Packet traversal: the 64 rays of a wave walk the BVH TOGETHER.  The current node, the stack and every
@@ -831,7 +766,19 @@ RT_FN void gen_range(const FrameCtl* ctl, int gen, long long capacity, uint32_t&
 // Primary rays: Camera::ray_for_pixel (src/camera.rs:62-72) with the inverse hoisted out of the pixel
 // loop.  Ray i of generation 0 is pixel (x,y) of this rank's tile list: 8x8 pixel blocks per wave.
 // ------------------------------------------------------------------------------------------------
+// a / b for 0 <= a < 2^23, 0 < b <= a's range, with inv_b = 1.f / b: the float product is within one of the
+// quotient, one correction step settles it.  (A 64-bit integer division costs some 100 instructions per ray.)
+RT_FN void div_small(uint32_t a, uint32_t b, float inv_b, uint32_t& q, uint32_t& r) {
+  q = (uint32_t)((float)a * inv_b);
+  int rem = (int)a - (int)(q * b);
+  if (rem < 0) --q, rem += (int)b;
+  else if (rem >= (int)b) ++q, rem -= (int)b;
+  r = (uint32_t)rem;
+}
+
 // tile_slot: the tile's place in this rank's output (frame-major over the batch); frame: which view.
+// Tile counts stay below 2^22 (canvas edges are at most 65536 pixels), batches below 2^6 frames; the host refuses
+// chains whose slot count would pass 2^23.
 template <class R>
 RT_FN bool pixel_of(const DevCamera<R>& cam, uint32_t i, int& x, int& y, int& tile_slot, int& in_tile, int& frame) {
   tile_slot = (int)(i / TILE_PIX);
@@ -839,13 +786,15 @@ RT_FN bool pixel_of(const DevCamera<R>& cam, uint32_t i, int& x, int& y, int& ti
   const int blk = j >> 6, lane = j & 63;
   const int xt = (blk & 3) * 8 + (lane & 7), yt = (blk >> 2) * 8 + (lane >> 3);
   in_tile = yt * TILE + xt;
-  int tile_local = tile_slot;
-  frame = 0;
-  if (cam.n_frames > 1) frame = tile_slot / cam.tiles_per_frame, tile_local = tile_slot - frame * cam.tiles_per_frame;
-  const long long tile = (long long)tile_local * cam.n_ranks + cam.rank;
-  if (tile >= cam.n_tiles) return false;
-  x = (int)(tile % cam.tiles_x) * TILE + xt;
-  y = (int)(tile / cam.tiles_x) * TILE + yt;
+  uint32_t tile_local = (uint32_t)tile_slot, f = 0;
+  if (cam.n_frames > 1) div_small((uint32_t)tile_slot, (uint32_t)cam.tiles_per_frame, cam.inv_tiles_per_frame, f, tile_local);
+  frame = (int)f;
+  const uint32_t tile = tile_local * (uint32_t)cam.n_ranks + (uint32_t)cam.rank;
+  if (tile >= (uint32_t)cam.n_tiles) return false;
+  uint32_t ty, tx;
+  div_small(tile, (uint32_t)cam.tiles_x, cam.inv_tiles_x, ty, tx);
+  x = (int)tx * TILE + xt;
+  y = (int)ty * TILE + yt;
   return x < cam.width && y < cam.height;
 }
 

@@ -111,6 +111,8 @@ struct rt355_ctx {
   int use_side = 1;     // shadow launches on the side stream (0: everything on the main stream, e.g. with several frames in flight)
   int quad = 0;         // generations beyond packet_gens, four lanes to a ray instead of one: bit 0 k_trace_q, bit 1 k_shadow_q
   int fused = 0;        // k_trace_spawn: trace + slot allocation + spawn of a generation in one launch (0: k_trace, k_scan, k_spawn)
+  uint32_t grid0_cap = 0;  // blocks of a generation-0 launch at most (set to 32 per CU at creation; 0: one block per 256 rays).  A capped grid
+                           // walks its rays in several trips, which spreads each wave's start-up (some 150 instructions) over more rays
   uint32_t fused_grid = 4096;  // blocks of a k_trace_spawn launch at most; larger generations take several chunks per block
   DevBuf org, dir, hit_t, hit_uv, hit_prim, color, mixr, child, blk_hits, blk_children, blk_base, ctl, io_in, io_out, io_out2;
   hipEvent_t ev[RT355_MAX_LAUNCH + 1] = {};  // timing mode: one before every launch, one behind the last
@@ -221,6 +223,8 @@ int dev_camera(const rt355_camera_desc* cams, int n_frames, int rank, int n_rank
   out.rank = rank, out.n_ranks = n_ranks;
   out.n_frames = n_frames;
   out.tiles_per_frame = (int32_t)((out.n_tiles + n_ranks - 1) / n_ranks);
+  out.inv_tiles_x = 1.f / (float)out.tiles_x, out.inv_tiles_per_frame = 1.f / (float)out.tiles_per_frame;
+  if ((int64_t)out.tiles_per_frame * n_frames >= (1 << 23)) return set_err(RT355_EINVAL, "batch: too many tiles for one launch chain");
   out.views = nullptr;
   return RT355_OK;
 }
@@ -295,7 +299,8 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, FrameC
   hipLaunchKernelGGL(k_reset_ctl, dim3(1), dim3(256), 0, c->stream, ctl, n_primary);
   const int depth = s->any_secondary ? max_depth : 0;  // no reflective / transparent material: one generation
   const int block = BLOCK;
-  const uint32_t grid0 = (n_primary + BLOCK - 1) / BLOCK;  // one block per 256 rays
+  uint32_t grid0 = (n_primary + BLOCK - 1) / BLOCK;  // one block per 256 rays
+  if (c->grid0_cap) grid0 = std::min(grid0, c->grid0_cap);
   const uint32_t grid_cap = (uint32_t)c->n_cu * 16;
   auto rec = [&](int kind, int gen) {
     if (c->timing && log.n < RT355_MAX_LAUNCH) HIP_TRY(hipEventRecord(c->ev[log.n], c->stream));
@@ -688,6 +693,7 @@ int rt355_ctx_create_ex(rt355_ctx** out, int device_id, int real_bits, int flags
   c->device = device_id, c->real_bits = real_bits;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+  c->grid0_cap = (uint32_t)c->n_cu * 32;
   // Main stream: the chain every generation waits on, at the highest priority the device offers.  Side
   // stream: the shadow launches, at the lowest, so that their waves yield to the chain's (measured: 2 % of
   // the frame).
@@ -727,6 +733,7 @@ int rt355_ctx_create_ex(rt355_ctx** out, int device_id, int real_bits, int flags
   if (const char* e = getenv("RT355_SHADOW_LAG")) c->shadow_lag = std::max(0, atoi(e));
   if (const char* e = getenv("RT355_QUAD")) c->quad = atoi(e) & 3;
   if (const char* e = getenv("RT355_FUSED")) c->fused = atoi(e) != 0;
+  if (const char* e = getenv("RT355_GRID0_CAP")) c->grid0_cap = (uint32_t)std::max(0, atoi(e));
   if (const char* e = getenv("RT355_FUSED_GRID")) c->fused_grid = (uint32_t)std::max(64, std::min(1 << 20, atoi(e)));
   *out = c;
   return RT355_OK;

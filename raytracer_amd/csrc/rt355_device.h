@@ -119,6 +119,7 @@ struct DevCamera {
   int32_t width, height, tiles_x, tiles_y, n_tiles;
   int32_t rank, n_ranks;
   int32_t n_frames, tiles_per_frame;
+  float inv_tiles_x, inv_tiles_per_frame;  // reciprocals for the index arithmetic (quotients are corrected by one step)
   const DevView<R>* views;
 };
 

@@ -5,12 +5,12 @@ tag=${1:-r02}
 out=gpurun_out/prof_$tag
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$out"
-# one frame at a time, so that each kernel's duration is its own (frames in flight overlap each other's kernels)
-timeout -s KILL 280 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o bench -- python3 bench.py --no-cpu-baseline --no-extra --in-flight 1 --steps 20 --warmup 3 > "$out/bench.log" 2>&1 || { tail -5 "$out/bench.log"; exit 1; }
+# one frame at a time, one chain in flight: each kernel's duration is its own (chains in flight overlap each other's kernels)
+timeout -s KILL 280 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o bench -- python3 bench.py --no-cpu-baseline --no-extra --in-flight 1 --batch 1 --steps 20 --warmup 3 > "$out/bench.log" 2>&1 || { tail -5 "$out/bench.log"; exit 1; }
 grep '^{' "$out/bench.log" | tail -1 > "$out/bench.json"
 f=$(find "$out" -name 'bench_kernel_stats.csv' | head -1)
 cp "$f" "$out/kernel_stats.csv" && head -12 "$out/kernel_stats.csv"
-# the default command (three frames in flight): same kernels, overlapped
+# the default command (several frames per chain, three chains in flight): the same kernels over larger generations, overlapped
 timeout -s KILL 280 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/k3" -o bench -- python3 bench.py --no-cpu-baseline --no-extra --steps 20 --warmup 3 > "$out/bench_k3.log" 2>&1 || { tail -5 "$out/bench_k3.log"; exit 1; }
 grep '^{' "$out/bench_k3.log" | tail -1 > "$out/bench_k3.json"
 cp "$(find "$out/k3" -name 'bench_kernel_stats.csv' | head -1)" "$out/kernel_stats_k3.csv"
