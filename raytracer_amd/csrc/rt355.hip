@@ -88,6 +88,8 @@ struct DevBuf {
 
 }  // namespace
 
+constexpr int64_t PACKET_SECONDARY_PRIMS = 64;  // scenes with at most this many reflective / transparent prims trace every generation in packets
+
 struct LaunchLog {
   int n = 0;
   int depth = 0;  // deepest generation
@@ -105,7 +107,12 @@ struct rt355_ctx {
   double pool_factor = 8.0;
   bool counting = false, timing = false;
   int exact_cones = 0;
-  int packet_gens = 1;  // generations 0..packet_gens-1 use the wave-packet traversal (primary rays and their shadow rays)
+  // Generations 0..packet_gens-1 use the wave-packet traversal, the later ones one lane per ray.  -1: chosen per scene --
+  // every generation when few prims can spawn secondary rays (their reflections and refractions leave a handful of
+  // surfaces and stay coherent: 5 to 7 % more frames per second on the teapot and glass scenes), generation 0 only
+  // otherwise (100 000 small reflective shapes scatter the rays: packets are 11 to 42 % slower there).
+  int packet_gens = -1;
+  bool throughput_chain = false;  // the chain being queued was begun without waiting, or carries several frames
   int combine_levels = 2;  // generations folded into the first combine launch by walking ray subtrees (0..3)
   int shadow_lag = 0;   // the shadow launch of generation g is released behind the spawn of generation g + lag
   int use_side = 1;     // shadow launches on the side stream (0: everything on the main stream, e.g. with several frames in flight)
@@ -134,6 +141,7 @@ struct rt355_scene {
   DevBuf nodes, prim_info, xform, tri, trin, materials;
   int32_t n_nodes = 0, n_bounded = 0, n_prims = 0, n_materials = 0, max_depth = 0;
   bool any_secondary = false, any_transparent = false;
+  int64_t n_secondary_prims = 0;  // prims whose material is reflective or transparent
   float light_pos[3], light_int[3];
   float box_abs_max = 0.f;
   size_t device_bytes = 0;
@@ -296,6 +304,10 @@ template <class R, bool COUNT>
 int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, FrameCtl* ctl, uint32_t n_primary, int max_depth, const DevCamera<R>& cam, bool primary,
                     int out_mode, float* out_dev, LaunchLog& log) {
   DevScene<R> sc = dev_scene<R>(s);
+  // Packets do more arithmetic per ray and stall less: best for the rate of chains that overlap (begun, not waited
+  // for) or carry several frames; one frame alone, whose every kernel ends on its slowest wave, is done soonest with
+  // packets for generations 0 and 1 only.
+  const int packet_gens = c->packet_gens >= 0 ? c->packet_gens : s->n_secondary_prims > PACKET_SECONDARY_PRIMS ? 1 : c->throughput_chain ? (int)RT355_MAX_GEN : 2;
   hipLaunchKernelGGL(k_reset_ctl, dim3(1), dim3(256), 0, c->stream, ctl, n_primary);
   const int depth = s->any_secondary ? max_depth : 0;  // no reflective / transparent material: one generation
   const int block = BLOCK;
@@ -315,7 +327,7 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, FrameC
     const uint32_t grid = g == 0 ? grid0 : std::min<uint32_t>(grid_cap, (uint32_t)((pool.capacity + BLOCK - 1) / BLOCK));
     int rc;
     if ((rc = rec(RT355_K_TRACE, g))) return rc;
-    const bool packet = g < c->packet_gens;
+    const bool packet = g < packet_gens;
     const bool quad = !packet && (c->quad & 1);
     const bool last = g == depth;
     const bool fused = c->fused && !quad;  // trace, slot allocation and spawn of the generation in one launch
@@ -367,7 +379,7 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, FrameC
       const uint32_t sgrid = sg == 0 ? grid0 : std::min<uint32_t>(grid_cap, (uint32_t)((pool.capacity + BLOCK - 1) / BLOCK));
       int rc2;
       if ((rc2 = rec(RT355_K_SHADE, sg))) return rc2;
-      if (sg < c->packet_gens)
+      if (sg < packet_gens)
         hipLaunchKernelGGL((k_shadow<R, COUNT, true>), dim3(sgrid), dim3(block), 0, st, sc, pool, ctl, sg, log.n);
       else if (c->quad & 2)
         hipLaunchKernelGGL((k_shadow_q<R, COUNT>), dim3(sgrid), dim3(block), 0, st, sc, pool, ctl, sg, log.n);
@@ -393,7 +405,7 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, FrameC
     }
   }
   log.depth = depth;
-  log.fused_last = !(depth >= c->packet_gens && (c->quad & 1));
+  log.fused_last = !(depth >= packet_gens && (c->quad & 1));
   log.fused = c->fused && !(c->quad & 1);
   if (overlap && depth > 0) {
     HIP_TRY(hipEventRecord(c->ev_side_done, c->side));
@@ -510,6 +522,7 @@ int render_impl(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam
     HIP_TRY(hipMemcpyAsync(c->views_dev, c->views_host, (size_t)n_frames * sizeof(DevView<R>), hipMemcpyHostToDevice, c->stream));
     dc.views = (const DevView<R>*)c->views_dev;
   }
+  c->throughput_chain = begin_only || n_frames > 1;
   auto t0 = std::chrono::steady_clock::now();
   LaunchLog log;
   if (c->counting)
@@ -553,6 +566,7 @@ int rays_impl(rt355_ctx* c, const rt355_scene* s, const float* rays_host, size_t
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RT355_OK;
   }
+  c->throughput_chain = false;
   auto t0 = std::chrono::steady_clock::now();
   if ((rc = c->io_out.ensure(n * 3 * sizeof(float)))) return rc;
   DevCamera<R> dummy;
@@ -592,6 +606,7 @@ int upload_impl(rt355_ctx* c, const HostScene& hs, rt355_scene* s) {
     for (int k = 0; k < 4; ++k) nodes[i].pad[k] = 0;
   }
   std::vector<PrimInfo> info(np);
+  int64_t n_secondary = 0;
   std::vector<DevXform<R>> xf(np);
   bool any_tri = false;
   for (size_t i = 0; i < np; ++i) {
@@ -601,6 +616,7 @@ int upload_impl(rt355_ctx* c, const HostScene& hs, rt355_scene* s) {
     if (hs.materials[p.material].reflective != 0.f) info[i].flags |= PF_REFLECTIVE;
     if (hs.materials[p.material].transparency != 0.f) info[i].flags |= PF_TRANSPARENT;
     if (hs.materials[p.material].reflective > 0.f && hs.materials[p.material].transparency > 0.f) info[i].flags |= PF_SCHLICK;
+    if (info[i].flags & (PF_REFLECTIVE | PF_TRANSPARENT)) n_secondary++;
     for (int k = 0; k < 12; ++k) xf[i].r[k] = (R)p.inv[k];
     xf[i].ymin = (R)p.ymin, xf[i].ymax = (R)p.ymax, xf[i].pad0 = xf[i].pad1 = 0;
     if ((p.flags & PF_KIND_MASK) >= RT355_TRIANGLE) any_tri = true;
@@ -644,6 +660,7 @@ int upload_impl(rt355_ctx* c, const HostScene& hs, rt355_scene* s) {
   if ((rc = put(s->materials, mats.data(), nm * sizeof(DevMaterial<R>)))) return rc;
   s->n_nodes = (int32_t)nn, s->n_bounded = hs.n_bounded, s->n_prims = (int32_t)np, s->n_materials = (int32_t)nm;
   s->max_depth = hs.max_depth, s->any_secondary = hs.any_secondary, s->any_transparent = hs.any_transparent;
+  s->n_secondary_prims = n_secondary;
   return RT355_OK;
 }
 

@@ -59,6 +59,17 @@ def render_tiles(scene, camera, max_depth, rank, world_size, out_tensor, stats=N
                                             C.c_void_p(out_tensor.data_ptr()), C.byref(stats) if stats is not None else None))
 
 
+def render_tiles_chain(scene, camera, max_depth, rank, world_size, out_tensor, stats=None):
+    """The same tiles through rt355_render_tiles_begin + rt355_frame_end: the launch plan of a chain that is begun
+    without waiting (what a frame loop runs), for measuring that plan one frame at a time."""
+    cd = camera.to_desc()
+    need = tiles_per_rank(int(camera.horizontal_size), int(camera.vertical_size), world_size) * TILE * TILE * 3
+    assert out_tensor.is_cuda and out_tensor.is_contiguous() and out_tensor.numel() == need
+    _abi.check(scene.lib.rt355_render_tiles_begin(scene.device.handle, scene.handle, C.byref(cd), max_depth, rank, world_size,
+                                                  C.c_void_p(out_tensor.data_ptr())))
+    _abi.check(scene.lib.rt355_frame_end(scene.device.handle, C.byref(stats) if stats is not None else None))
+
+
 def render_canvas(scene, camera, max_depth, out_tensor, stats=None):
     """The whole frame, row-major, into `out_tensor` (a CUDA float32 tensor of height*width*3 elements):
     what a single rank does, where there is nothing to gather or un-tile."""

@@ -33,6 +33,6 @@ dev = Device.get(0, a.real)
 scene = dev.upload(world)
 out = torch.empty(rd.tiles_per_rank(a.width, a.height, 1) * 1024 * 3, dtype=torch.float32, device="cuda")
 for _ in range(a.frames):
-    rd.render_tiles(scene, cam, 5, 0, 1, out)
+    rd.render_tiles_chain(scene, cam, 5, 0, 1, out)  # the launch plan of a frame loop's chains
 torch.cuda.synchronize()
 print("frames done")

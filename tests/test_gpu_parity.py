@@ -304,8 +304,9 @@ def test_render_is_deterministic(dev):
 
 @pytest.mark.parametrize("env", [{"RT355_FUSED": "1"}, {"RT355_QUAD": "3"}, {"RT355_QUAD": "1"}, {"RT355_PACKET_GENS": "0", "RT355_QUAD": "3"},
                                  {"RT355_PACKET_GENS": "0"}, {"RT355_PACKET_GENS": "6"}, {"RT355_FUSED": "1", "RT355_FUSED_GRID": "64"},
-                                 {"RT355_COMBINE_LEVELS": "0"}],
-                         ids=["fused", "quad", "quad-trace", "quad-all", "per-lane-all", "packet-all", "fused-multichunk", "combine-per-generation"])
+                                 {"RT355_COMBINE_LEVELS": "0"}, {"RT355_PACKET_GENS": "1"}],
+                         ids=["fused", "quad", "quad-trace", "quad-all", "per-lane-all", "packet-all", "fused-multichunk", "combine-per-generation",
+                              "packet-primary-only"])
 @pytest.mark.parametrize("real_bits", [64, 32])
 def test_every_launch_plan_renders_the_same_image(env, real_bits):
     """The frame can be run through other kernels than the default ones (chosen at context creation from the
