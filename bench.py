@@ -2,7 +2,7 @@
 workload -- teapot-high (6 320 smooth triangles) on a reflective checker floor next to a glass sphere,
 shadows, reflection / refraction depth 5, 1920x1080 -- on N MI355X of one node.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 240 --warmup 24
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -63,8 +63,8 @@ def cpu_baseline(world, cam, depth):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=240)
+    ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--scene", default="north_star")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -99,7 +99,11 @@ def main():
     # K frames are kept in flight on each GPU (one context per frame in flight): every step begins a frame and
     # completes the one begun K steps earlier; the flush before each fence completes the rest, so exactly
     # `steps` whole frames (render + gather + un-tile) lie between the two fences.
-    loop = rd.FrameLoop(scene, dev, w, h, rank, world_size, args.depth, in_flight=args.in_flight, batch=args.batch if args.batch > 0 else max(4, world_size))
+    # frames per chain: at least a whole frame's worth of tiles per rank, as long as one chain's ray pool (8 ray slots
+    # per primary ray, 116 B each in f64) stays below 16 GB
+    pool_bytes_per_frame = rd.tiles_per_rank(w, h, world_size) * rd.TILE * rd.TILE * 8 * (116 if args.real == 64 else 64)
+    batch = args.batch if args.batch > 0 else max(1, min(max(4, world_size), int(16e9 // pool_bytes_per_frame)))
+    loop = rd.FrameLoop(scene, dev, w, h, rank, world_size, args.depth, in_flight=args.in_flight, batch=batch)
     local = torch.empty(rd.tiles_per_rank(w, h, world_size) * rd.TILE * rd.TILE * 3, dtype=torch.float32, device="cuda")
     st = Stats()
 
