@@ -131,6 +131,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     # one frame alone, begun and waited for (no other frame in flight): the latency beside the rate
+    rd.render_tiles(scene, cam, args.depth, rank, world_size, local, st)  # this context's pool is allocated here
     t1 = time.perf_counter()
     for _ in range(5):
         rd.render_tiles(scene, cam, args.depth, rank, world_size, local, st)
@@ -174,14 +175,16 @@ def main():
         dev.set_timing(True)
         n_prof = 5
         acc = None
-        for _ in range(n_prof):  # the launch plan of the timed loop (a chain begun without waiting), one frame at a time
-            rd.render_tiles_chain(scene, cam, args.depth, rank, world_size, local, st)
+        # the chains of the timed loop (loop.B frames each, begun without waiting), one at a time on one stream
+        chain_out = torch.empty(loop.B * local.numel(), dtype=torch.float32, device="cuda")
+        for _ in range(n_prof):
+            rd.render_tiles_chain(scene, [cam] * loop.B, args.depth, rank, world_size, chain_out, st)
             ms_l = np.array(st.launch_ms[: st.n_launch], dtype=np.float64)
             acc = ms_l if acc is None else acc + ms_l
         dev.set_timing(False)
         ms_l = acc / n_prof
         dev.set_counting(True)
-        rd.render_tiles_chain(scene, cam, args.depth, rank, world_size, local, st)
+        rd.render_tiles_chain(scene, [cam] * loop.B, args.depth, rank, world_size, chain_out, st)
         dev.set_counting(False)
         flops = np.array(st.launch_flops[: st.n_launch], dtype=np.float64)
         box_flops = 24.0 * np.array(st.launch_box_tests[: st.n_launch], dtype=np.float64)  # box tests run in f32
@@ -194,7 +197,7 @@ def main():
         achieved = flops[k] / (ms_l[k] * 1e-3) / 1e12
         kernel_name = f"{KIND_NAME.get(kinds[k], '?')} generation {gens[k]}"
         headline = (args.scene, w, h, args.depth, args.real, world_size) == ("north_star", 1920, 1080, 5, 64, 1)
-        counters = _measured_counters(kernel_name) if headline else None
+        counters = _measured_counters(kernel_name, loop.B) if headline else None
         traffic = int(counters["hbm_bytes"]) if counters else None
         out["roofline"] = {
             "bound": "valu_fp64" if args.real == 64 else "valu_fp32",
@@ -210,11 +213,13 @@ def main():
             "flops_per_launch_f64_part": float(flops[k] - box_flops[k]),
             "flops_per_launch_f32_boxes": float(box_flops[k]),
             "launch_ms": round(float(ms_l[k]), 4),
-            "frame_flops": float(flops.sum()),
-            "frame_flops_f64_part": float((flops - box_flops).sum()),
-            "frame_kernel_ms": round(float(ms_l.sum()), 4),
-            # whole frame against the peak, by the wall time of the timed region (launches overlap on two streams)
-            "frame_frac": round(float(flops.sum() / (ms * 1e-3) / 1e12 / peak), 5),
+            # a launch works on a chain of this many frames: the per-launch figures above and below are per chain
+            "frames_per_launch": loop.B,
+            "frame_flops": float(flops.sum() / loop.B),
+            "frame_flops_f64_part": float((flops - box_flops).sum() / loop.B),
+            "frame_kernel_ms": round(float(ms_l.sum() / loop.B), 4),
+            # whole frame against the peak, by the wall time of the timed region (chains overlap)
+            "frame_frac": round(float(flops.sum() / loop.B / (ms * 1e-3) / 1e12 / peak), 5),
             "launches": [{"kernel": KIND_NAME.get(kinds[i], "?"), "gen": gens[i], "ms": round(float(ms_l[i]), 4),
                           "gflop": round(float(flops[i]) / 1e9, 4), "gflop_f32_boxes": round(float(box_flops[i]) / 1e9, 4),
                           "max_box_tests_one_lane": int(maxbox[i])} for i in range(len(kinds))],
@@ -267,14 +272,14 @@ def source_hash():
     return hsh.hexdigest()[:16]
 
 
-def _measured_counters(kernel_name):
+def _measured_counters(kernel_name, frames_per_chain):
     """Hardware-counter figures of one launch of the named kernel on the headline workload, from the committed PMC
     passes (a bench run cannot collect hardware counters itself).  None when there is no such measurement or
-    when it was taken on other kernel sources than the ones in the tree."""
+    when it was taken on other kernel sources than the ones in the tree or on chains of another length."""
     try:
         with open(os.path.join(ROOT, "profiles", "r02_counters.json")) as fh:
             doc = json.load(fh)
-        if doc.get("source_hash") != source_hash():
+        if doc.get("source_hash") != source_hash() or doc.get("frames_per_chain") != frames_per_chain:
             return None
         c = dict(doc["launches"][kernel_name])
         c["source"] = "profiles/r02_counters.json"

@@ -59,14 +59,16 @@ def render_tiles(scene, camera, max_depth, rank, world_size, out_tensor, stats=N
                                             C.c_void_p(out_tensor.data_ptr()), C.byref(stats) if stats is not None else None))
 
 
-def render_tiles_chain(scene, camera, max_depth, rank, world_size, out_tensor, stats=None):
-    """The same tiles through rt355_render_tiles_begin + rt355_frame_end: the launch plan of a chain that is begun
-    without waiting (what a frame loop runs), for measuring that plan one frame at a time."""
-    cd = camera.to_desc()
-    need = tiles_per_rank(int(camera.horizontal_size), int(camera.vertical_size), world_size) * TILE * TILE * 3
+def render_tiles_chain(scene, cameras, max_depth, rank, world_size, out_tensor, stats=None):
+    """One launch chain the way a frame loop runs it (rt355_render_tiles_batch_begin + rt355_frame_end: begun
+    without waiting, one or several frames of one size), for measuring that plan one chain at a time.  `cameras`: a
+    camera or a list of them; `out_tensor` holds the tiles of all the frames, frame after frame."""
+    cams = list(cameras) if isinstance(cameras, (list, tuple)) else [cameras]
+    cds = (_abi.CameraDesc * len(cams))(*[c.to_desc() for c in cams])
+    need = len(cams) * tiles_per_rank(int(cams[0].horizontal_size), int(cams[0].vertical_size), world_size) * TILE * TILE * 3
     assert out_tensor.is_cuda and out_tensor.is_contiguous() and out_tensor.numel() == need
-    _abi.check(scene.lib.rt355_render_tiles_begin(scene.device.handle, scene.handle, C.byref(cd), max_depth, rank, world_size,
-                                                  C.c_void_p(out_tensor.data_ptr())))
+    _abi.check(scene.lib.rt355_render_tiles_batch_begin(scene.device.handle, scene.handle, cds, len(cams), max_depth, rank, world_size,
+                                                        C.c_void_p(out_tensor.data_ptr())))
     _abi.check(scene.lib.rt355_frame_end(scene.device.handle, C.byref(stats) if stats is not None else None))
 
 

@@ -1,5 +1,5 @@
-"""rocprofv3 --pmc passes over one frame (scripts/pmc.sh) -> profiles-style JSON keyed by launch:
-   python scripts/make_counters.py <pmc_dir> <out.json>
+"""rocprofv3 --pmc passes over one launch chain (scripts/pmc.sh) -> profiles-style JSON keyed by launch:
+   python scripts/make_counters.py <pmc_dir> <out.json> [frames_per_chain]
 HBM bytes follow the gfx950 convention for FETCH_SIZE / WRITE_SIZE (KiB; wide reads counted at half size, so
 FETCH_SIZE x 2).  The file is stamped with a hash of the device sources; bench.py quotes it only when the hash
 matches the tree."""
@@ -50,7 +50,9 @@ for i in sorted(rows):
     e["valu_instructions"] = int(g("SQ_INSTS_VALU"))
     launches[f"{base} generation {gen}"] = e
 import bench
-doc = {"source": "rocprofv3 --pmc, one pass per counter set (scripts/pmc.sh), north_star 1920x1080 depth 5 f64, 1 GPU, one frame; per launch",
+frames = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+doc = {"source": f"rocprofv3 --pmc, one pass per counter set (scripts/pmc.sh), north_star 1920x1080 depth 5 f64, 1 GPU, one launch chain of {frames} frames; per launch",
+       "frames_per_chain": frames,
        "correction": "hbm_bytes = (FETCH_SIZE x 2 + WRITE_SIZE) KiB: gfx950 counts wide reads at half size",
        "source_hash": bench.source_hash(), "launches": launches}
 json.dump(doc, open(out_path, "w"), indent=1)

@@ -13,7 +13,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--scene", default="north_star")
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
-ap.add_argument("--frames", type=int, default=3)
+ap.add_argument("--frames", type=int, default=3, help="launch chains to run")
+ap.add_argument("--batch", type=int, default=4, help="frames per launch chain (the bench default at one GPU)")
 ap.add_argument("--real", type=int, default=64)
 ap.add_argument("--keep", default="", help="diagnostic: keep only these shapes of the scene: floor, sphere, mesh (comma list); 'matte' also makes every material non-reflective and opaque")
 a = ap.parse_args()
@@ -31,8 +32,8 @@ if a.keep:
     print("shapes kept:", len(world.shapes))
 dev = Device.get(0, a.real)
 scene = dev.upload(world)
-out = torch.empty(rd.tiles_per_rank(a.width, a.height, 1) * 1024 * 3, dtype=torch.float32, device="cuda")
+out = torch.empty(a.batch * rd.tiles_per_rank(a.width, a.height, 1) * 1024 * 3, dtype=torch.float32, device="cuda")
 for _ in range(a.frames):
-    rd.render_tiles_chain(scene, cam, 5, 0, 1, out)  # the launch plan of a frame loop's chains
+    rd.render_tiles_chain(scene, [cam] * a.batch, 5, 0, 1, out)  # a chain of a frame loop
 torch.cuda.synchronize()
 print("frames done")
