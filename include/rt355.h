@@ -235,6 +235,10 @@ int rt355_render_tiles_batch_begin(rt355_ctx*, const rt355_scene*, const rt355_c
                                    int max_depth, int rank, int n_ranks, float* tiles_out_dev);
 int rt355_render_device_batch_begin(rt355_ctx*, const rt355_scene*, const rt355_camera_desc* cams, int n_frames,
                                     int max_depth, float* rgb_out_dev);
+/* The same chain, waited for, with the canvases copied to HOST memory: rgb_out receives n_frames canvases of
+ * rt355_render, one after the other (Camera::render, src/camera.rs:74-88, called once per camera). */
+int rt355_render_batch(rt355_ctx*, const rt355_scene*, const rt355_camera_desc* cams, int n_frames, int max_depth,
+                       float* rgb_out, rt355_stats* stats /* nullable */);
 /* Number of tiles each rank owns (tile count padded up to a multiple of n_ranks). */
 int64_t rt355_tiles_per_rank(const rt355_camera_desc* cam, int n_ranks);
 /* Rank 0, after the gather: `gathered_dev` holds n_ranks consecutive rank buffers; scatters them

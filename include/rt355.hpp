@@ -18,6 +18,7 @@
 #ifndef RT355_HPP
 #define RT355_HPP
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <fstream>
@@ -461,6 +462,9 @@ class Scene {
   Scene(const Scene&) = delete;
   Scene& operator=(const Scene&) = delete;
   inline Canvas render(const Camera& camera, int max_depth = 5, rt355_stats* stats = nullptr) const;
+  // Camera::render for every camera of a path (all of one image size), in launch chains of up to RT355_MAX_BATCH
+  // frames whose rays are traced together (rt355_render_batch).
+  inline std::vector<Canvas> render_path(const std::vector<Camera>& cameras, int max_depth = 5) const;
 
  private:
   Device& dev_;
@@ -513,6 +517,27 @@ inline Canvas Scene::render(const Camera& camera, int max_depth, rt355_stats* st
   c.pixels.resize(c.width * c.height);
   for (size_t i = 0; i < c.pixels.size(); ++i) c.pixels[i] = Color::rgb(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
   return c;
+}
+
+inline std::vector<Canvas> Scene::render_path(const std::vector<Camera>& cameras, int max_depth) const {
+  std::vector<Canvas> out;
+  for (size_t first = 0; first < cameras.size(); first += RT355_MAX_BATCH) {
+    const size_t n = std::min<size_t>(RT355_MAX_BATCH, cameras.size() - first);
+    std::vector<rt355_camera_desc> cds;
+    for (size_t f = 0; f < n; ++f) cds.push_back(cameras[first + f].desc());
+    const size_t w = (size_t)cameras[first].horizontal_size(), h = (size_t)cameras[first].vertical_size();
+    std::vector<float> rgb(n * w * h * 3);
+    check(rt355_render_batch(dev_.handle(), scene_, cds.data(), (int)n, max_depth, rgb.data(), nullptr));
+    for (size_t f = 0; f < n; ++f) {
+      Canvas c;
+      c.width = w, c.height = h;
+      c.pixels.resize(w * h);
+      const float* px = rgb.data() + f * w * h * 3;
+      for (size_t i = 0; i < w * h; ++i) c.pixels[i] = Color::rgb(px[3 * i], px[3 * i + 1], px[3 * i + 2]);
+      out.push_back(std::move(c));
+    }
+  }
+  return out;
 }
 
 }  // namespace raytracer

@@ -113,6 +113,7 @@ SYMBOLS = [
     ("rt355_frame_end", C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     ("rt355_render_tiles_batch_begin", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("rt355_render_device_batch_begin", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_int, C.c_void_p]),
+    ("rt355_render_batch", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_int, C.c_void_p, C.POINTER(Stats)]),
     ("rt355_tiles_per_rank", C.c_int64, [C.POINTER(CameraDesc), C.c_int]),
     ("rt355_untile", C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_void_p, C.c_void_p]),
     ("rt355_untile_u8", C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_void_p, C.c_void_p]),

@@ -910,6 +910,19 @@ int rt355_render(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* ca
   return RT355_OK;
 }
 
+int rt355_render_batch(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cams, int n_frames, int max_depth, float* rgb_out, rt355_stats* stats) {
+  int rc = check_batch_args(c, s, cams, n_frames, max_depth);
+  if (rc) return rc;
+  if (!rgb_out) return set_err(RT355_EINVAL, "null output");
+  const size_t n = (size_t)(int)cams->hsize * (size_t)(int)cams->vsize * 3 * (size_t)n_frames;
+  if ((rc = c->io_out.ensure(n * sizeof(float)))) return rc;
+  rc = c->real_bits == 32 ? render_impl<float>(c, s, cams, max_depth, 0, 1, OUT_ROWMAJOR, (float*)c->io_out.p, stats, false, false, n_frames)
+                          : render_impl<double>(c, s, cams, max_depth, 0, 1, OUT_ROWMAJOR, (float*)c->io_out.p, stats, false, false, n_frames);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(rgb_out, c->io_out.p, n * sizeof(float), hipMemcpyDeviceToHost));
+  return RT355_OK;
+}
+
 int rt355_render_u8(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam, int max_depth, uint8_t* rgb_out, rt355_stats* stats) {
   int rc = check_render_args(c, s, cam, max_depth);
   if (rc) return rc;

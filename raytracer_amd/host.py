@@ -386,6 +386,21 @@ class Scene:
                                          C.byref(stats) if stats is not None else None))
         return Canvas(w, h, out)
 
+    def render_path(self, cameras, max_depth=5, stats=None):
+        """`Camera::render` for every camera of a path (all of one image size) in launch chains of up to
+        RT355_MAX_BATCH frames: the rays of a chain's frames are traced together.  Returns one Canvas per camera."""
+        cameras = list(cameras)
+        out = []
+        for i in range(0, len(cameras), _abi.MAX_BATCH):
+            part = cameras[i:i + _abi.MAX_BATCH]
+            w, h = int(part[0].horizontal_size), int(part[0].vertical_size)
+            buf = np.empty((len(part), h, w, 3), dtype=np.float32)
+            cds = (_abi.CameraDesc * len(part))(*[c.to_desc() for c in part])
+            _abi.check(self.lib.rt355_render_batch(self.device.handle, self.handle, cds, len(part), max_depth, buf.ctypes.data,
+                                                   C.byref(stats) if stats is not None else None))
+            out += [Canvas(w, h, buf[f]) for f in range(len(part))]
+        return out
+
     def render_u8(self, camera, max_depth=5, stats=None):
         """Camera::render + Color::to_u8 on the device: (height, width, 3) uint8, the body of a binary PPM."""
         w, h = int(camera.horizontal_size), int(camera.vertical_size)

@@ -142,6 +142,8 @@ extern "C" {
                                           tiles_out_dev: *mut f32) -> c_int;
     pub fn rt355_render_device_batch_begin(ctx: *mut rt355_ctx, scene: *const rt355_scene, cams: *const rt355_camera_desc,
                                            n_frames: c_int, max_depth: c_int, rgb_out_dev: *mut f32) -> c_int;
+    pub fn rt355_render_batch(ctx: *mut rt355_ctx, scene: *const rt355_scene, cams: *const rt355_camera_desc,
+                              n_frames: c_int, max_depth: c_int, rgb_out: *mut f32, stats: *mut rt355_stats) -> c_int;
     pub fn rt355_tiles_per_rank(cam: *const rt355_camera_desc, n_ranks: c_int) -> i64;
     pub fn rt355_untile(ctx: *mut rt355_ctx, cam: *const rt355_camera_desc, n_ranks: c_int,
                         gathered_dev: *const f32, rgb_out_dev: *mut f32) -> c_int;

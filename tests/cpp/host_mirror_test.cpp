@@ -210,6 +210,17 @@ static void gpu_tests(const char* out_path) {
     }
     CHECK(same && lit);
     CHECK(a.to_ppm().rfind("P3\n200 150\n255\n", 0) == 0);
+    // a camera path through one launch chain: every frame equals its own render
+    {
+      const Camera c2(200, 150, PI / 3, Vector4::point(0.5f, 1.5f, -5).view_transformation(Vector4::point(0, 1, 0), Vector4::vector(0, 1, 0)));
+      const std::vector<Canvas> path = scene.render_path({c, c2, c});
+      const Canvas b2 = scene.render(c2);
+      CHECK(path.size() == 3);
+      bool eq = path.size() == 3;
+      for (size_t i = 0; eq && i < a.pixels.size(); ++i)
+        eq = path[0].pixels[i].r == a.pixels[i].r && path[1].pixels[i].g == b2.pixels[i].g && path[2].pixels[i].b == a.pixels[i].b;
+      CHECK(eq);
+    }
     if (out_path) {
       FILE* f = std::fopen(out_path, "wb");
       CHECK(f != nullptr);

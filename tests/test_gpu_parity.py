@@ -671,6 +671,8 @@ def test_batch_of_frames_in_one_launch_chain(real_bits):
             want = scene.render(c, 5).pixels
             assert np.array_equal(canvases[f].cpu().numpy(), want), f
             assert np.array_equal(direct[f].cpu().numpy(), want), f
+        paths = scene.render_path(cams, 5)  # rt355_render_batch: the same chain, canvases on the host
+        assert len(paths) == len(cams) and all(np.array_equal(paths[f].pixels, scene.render(c, 5).pixels) for f, c in enumerate(cams))
         # one size per chain
         other = Camera(w + 32, h, math.pi / 3, cam0.transform)
         bad = (_abi.CameraDesc * 2)(cam0.to_desc(), other.to_desc())
