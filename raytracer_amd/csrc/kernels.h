@@ -885,7 +885,7 @@ RT_FN void trace_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* 
 // and the child bound for k_scan; with `count_hits` set it adds the hits to the generation's total itself
 // (no k_scan launch follows: the frame runs the fused kernels and this is its deepest generation).
 template <class R, bool COUNT, bool PACKET, bool LAST>
-__global__ void __launch_bounds__(256, (PACKET && !LAST) ? 4 : RT355_WPS_LANE) k_trace(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch, DevCamera<R> cam, int primary, int count_hits) {
+__global__ void __launch_bounds__(256, PACKET ? (LAST ? RT355_WPS_PACKET_LAST : RT355_WPS_PACKET) : RT355_WPS_LANE) k_trace(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch, DevCamera<R> cam, int primary, int count_hits) {
   __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
   int* lds = PACKET ? lds_stack + (threadIdx.x >> 6) * STACK_DEPTH : lds_stack + threadIdx.x;
   uint32_t start, count;
@@ -1272,7 +1272,7 @@ RT_FN void container_indices(const DevScene<R>& sc, bool need, int p, PrimInfo i
 // One thread per ray; lanes whose ray missed idle.
 // ------------------------------------------------------------------------------------------------
 template <class R, bool COUNT, bool PACKET>
-__global__ void __launch_bounds__(256, PACKET ? 4 : RT355_WPS_LANE) k_shadow(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int launch) {
+__global__ void __launch_bounds__(256, PACKET ? RT355_WPS_PACKET : RT355_WPS_LANE) k_shadow(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int launch) {
   uint32_t start, gcount;
   gen_range(ctl, gen, pool.capacity, start, gcount);
   __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
@@ -1461,7 +1461,7 @@ RT_FN void spawn_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* 
 }
 
 template <class R, bool COUNT, bool PACKET>
-__global__ void __launch_bounds__(256, RT355_WPS_SPAWN) k_spawn(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int any_transparent, int launch) {
+__global__ void __launch_bounds__(256, PACKET ? RT355_WPS_SPAWN_PACKET : RT355_WPS_SPAWN) k_spawn(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int any_transparent, int launch) {
   __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
   int* lds = PACKET ? lds_stack + (threadIdx.x >> 6) * STACK_DEPTH : lds_stack + threadIdx.x;
   Work wk;

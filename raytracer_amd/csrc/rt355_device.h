@@ -27,6 +27,16 @@ constexpr int BLOCK = 256;           // threads per block of the traversal kerne
 #ifndef RT355_WPS_SPAWN
 #define RT355_WPS_SPAWN 3
 #endif
+// the same for the packet kernels (fewer live registers: node and triangle records sit in scalar registers)
+#ifndef RT355_WPS_PACKET
+#define RT355_WPS_PACKET 4
+#endif
+#ifndef RT355_WPS_PACKET_LAST
+#define RT355_WPS_PACKET_LAST 3
+#endif
+#ifndef RT355_WPS_SPAWN_PACKET
+#define RT355_WPS_SPAWN_PACKET 3
+#endif
 constexpr uint32_t LEAF_FIRST_MASK = 0x1FFFFFFu;  // leaf reference ~c: first | tri-only flag << 25 | count << 26
 constexpr uint32_t LEAF_TRI_BIT = 1u << 25;       // every prim of the leaf is a triangle with identity transform
 constexpr int MAX_TREE_DEPTH = 40;   // of the binary tree the builder collapses; a 4-wide node pushes up to 3 entries
