@@ -9,8 +9,8 @@ shadows, reflection / refraction depth 5, 1920x1080 -- on N MI355X of one node.
 A step is ONE frame: every rank renders its 32x32 tiles (tile t -> rank t % N, scene replicated), the
 rank tile buffers are gathered to rank 0 (torch.distributed.gather = RCCL over xGMI) and un-tiled there;
 with one rank the canvas is written row-major in place (same kernels, no gather).  Frames are pipelined:
---batch B frames share one launch chain (default: max(4, N), so that a rank's chain carries at least a whole
-frame's worth of tiles whatever N is) and --in-flight K (default 3) chains are in flight on every GPU; a step adds one frame and
+--batch B frames share one launch chain (default: max(8, N), so that a rank's chain carries at least a whole
+frame's worth of tiles whatever N is, bounded by 16 GB of ray pool per chain) and --in-flight K (default 3) chains are in flight on every GPU; a step adds one frame and
 hands back the oldest finished one, and the timed region ends with a flush, so it holds exactly `steps`
 complete frames.
 The scene is uploaded once, before the timed region; all inputs are resident in HBM when timing starts.
@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--real", type=int, default=64, choices=[32, 64])
     ap.add_argument("--in-flight", type=int, default=3, help="frames kept in flight on each GPU (1: every step waits for its own frame)")
-    ap.add_argument("--batch", type=int, default=0, help="frames per launch chain (0: max(4, number of GPUs))")
+    ap.add_argument("--batch", type=int, default=0, help="frames per launch chain (0: max(8, number of GPUs), bounded by 16 GB of ray pool per chain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the 3840x2160 figure that is reported beside the headline")
     ap.add_argument("--rehearse", action="store_true",
@@ -102,7 +102,7 @@ def main():
     # frames per chain: at least a whole frame's worth of tiles per rank, as long as one chain's ray pool (8 ray slots
     # per primary ray, 116 B each in f64) stays below 16 GB
     pool_bytes_per_frame = rd.tiles_per_rank(w, h, world_size) * rd.TILE * rd.TILE * 8 * (116 if args.real == 64 else 64)
-    batch = args.batch if args.batch > 0 else max(1, min(max(4, world_size), int(16e9 // pool_bytes_per_frame)))
+    batch = args.batch if args.batch > 0 else max(1, min(max(8, world_size), int(16e9 // pool_bytes_per_frame)))
     loop = rd.FrameLoop(scene, dev, w, h, rank, world_size, args.depth, in_flight=args.in_flight, batch=batch)
     local = torch.empty(rd.tiles_per_rank(w, h, world_size) * rd.TILE * rd.TILE * 3, dtype=torch.float32, device="cuda")
     st = Stats()

@@ -138,7 +138,7 @@ class FrameLoop:
         self.tensor_device = tensor_device
         # with one rank and a float canvas the frames are written row-major in place: nothing to gather or un-tile
         self.direct = self.cuda and render is None and world_size == 1 and not as_u8
-        if render is None and K > 1:
+        if render is None and (K > 1 or B > 1):  # chains meant to overlap or to carry several frames: one stream each
             from .host import Device
             self.ctxs = [Device(device.device_id, device.real_bits, flags=_abi.CTX_ONE_STREAM) for _ in range(K)]
             self._own_ctxs = True
