@@ -273,6 +273,10 @@ void rt355_multi_destroy(rt355_multi*);
 int rt355_multi_upload(rt355_multi*, const rt355_shape_desc* shapes, size_t n_shapes, const rt355_light_desc* light);
 int rt355_multi_render(rt355_multi*, const rt355_camera_desc* cam, int max_depth, float* rgb_out,
                        rt355_stats* stats /* nullable */);
+/* n_frames cameras of one image size in one launch chain per device (rt355_render_tiles_batch_begin on each): what
+ * keeps 8 GPUs busy on frames of which each renders an eighth.  rgb_out: n_frames canvases, one after the other. */
+int rt355_multi_render_batch(rt355_multi*, const rt355_camera_desc* cams, int n_frames, int max_depth, float* rgb_out,
+                             rt355_stats* stats /* nullable */);
 const char* rt355_multi_gather_kind(const rt355_multi*);
 
 /* World::color_at(ray, max_depth) (src/world.rs:58-66) for caller-supplied rays: rays is n*6

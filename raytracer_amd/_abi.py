@@ -104,6 +104,7 @@ SYMBOLS = [
     ("rt355_multi_destroy", None, [C.c_void_p]),
     ("rt355_multi_upload", C.c_int, [C.c_void_p, C.POINTER(ShapeDesc), C.c_size_t, C.POINTER(LightDesc)]),
     ("rt355_multi_render", C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_void_p, C.POINTER(Stats)]),
+    ("rt355_multi_render_batch", C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_int, C.c_void_p, C.POINTER(Stats)]),
     ("rt355_multi_gather_kind", C.c_char_p, [C.c_void_p]),
     ("rt355_render_device", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_void_p, C.POINTER(Stats)]),
     ("rt355_render_device_noalloc", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CameraDesc), C.c_int, C.c_void_p, C.POINTER(Stats)]),

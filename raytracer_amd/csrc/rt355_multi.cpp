@@ -168,12 +168,18 @@ int rt355_multi_upload(rt355_multi* m, const rt355_shape_desc* shapes, size_t n_
 }
 
 int rt355_multi_render(rt355_multi* m, const rt355_camera_desc* cam, int max_depth, float* rgb_out, rt355_stats* stats) {
+  return rt355_multi_render_batch(m, cam, 1, max_depth, rgb_out, stats);
+}
+
+int rt355_multi_render_batch(rt355_multi* m, const rt355_camera_desc* cam, int n_frames, int max_depth, float* rgb_out, rt355_stats* stats) {
   if (!m || !cam || !rgb_out) return fail(RT355_EINVAL, "null argument");
+  if (n_frames < 1 || n_frames > RT355_MAX_BATCH) return fail(RT355_EINVAL, "batch: between 1 and RT355_MAX_BATCH frames");
   if (!m->scene[0]) return fail(RT355_EINVAL, "no scene uploaded");
   const int64_t tpr = rt355_tiles_per_rank(cam, m->n);
   if (tpr < 0) return fail(RT355_EINVAL, "camera: hsize and vsize must be finite and in [1, 65536]");
-  const size_t count = (size_t)tpr * rt355::TILE_PIX * 3;
-  const size_t canvas_floats = (size_t)(int)cam->hsize * (size_t)(int)cam->vsize * 3;
+  // per device: the tiles of all the frames, frame after frame; on device 0: the same for every device, then the canvases
+  const size_t count = (size_t)tpr * rt355::TILE_PIX * 3 * (size_t)n_frames;
+  const size_t canvas_floats = (size_t)(int)cam->hsize * (size_t)(int)cam->vsize * 3 * (size_t)n_frames;
   auto t0 = std::chrono::steady_clock::now();
   if (count > m->tiles_floats || canvas_floats > m->canvas_floats) {  // first frame of a larger size
     for (int d = 0; d < m->n; ++d) {
@@ -201,7 +207,8 @@ int rt355_multi_render(rt355_multi* m, const rt355_camera_desc* cam, int max_dep
     for (int d = 0; d < m->n; ++d)
       th.emplace_back([&, d]() {
         float* dst = d == 0 ? m->gathered : m->tiles[d];
-        rcs[d] = rt355_render_tiles(m->ctx[d], m->scene[d], cam, max_depth, d, m->n, dst, &st[d]);
+        rcs[d] = rt355_render_tiles_batch_begin(m->ctx[d], m->scene[d], cam, n_frames, max_depth, d, m->n, dst);
+        if (!rcs[d]) rcs[d] = rt355_frame_end(m->ctx[d], &st[d]);
         if (rcs[d]) errs[d] = rt355_last_error();
       });
     for (auto& t : th) t.join();
@@ -235,7 +242,7 @@ int rt355_multi_render(rt355_multi* m, const rt355_camera_desc* cam, int max_dep
       MHIP(hipStreamSynchronize(m->stream[0]));
     }
   }
-  int rc = rt355_untile(m->ctx[0], cam, m->n, m->gathered, m->canvas);
+  int rc = rt355_untile_batch(m->ctx[0], cam, m->n, n_frames, m->gathered, m->canvas);
   if (rc) return rc;
   MHIP(hipSetDevice(m->dev[0]));
   MHIP(hipMemcpy(rgb_out, m->canvas, canvas_floats * sizeof(float), hipMemcpyDeviceToHost));

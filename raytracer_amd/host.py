@@ -355,6 +355,21 @@ class MultiDevice:
                                                C.byref(stats) if stats is not None else None))
         return Canvas(w, h, out)
 
+    def render_path(self, cameras, max_depth=5, stats=None):
+        """Camera::render for every camera of a path (one image size): each device renders its tiles of up to
+        RT355_MAX_BATCH frames in one launch chain."""
+        cameras = list(cameras)
+        out = []
+        for i in range(0, len(cameras), _abi.MAX_BATCH):
+            part = cameras[i:i + _abi.MAX_BATCH]
+            w, h = int(part[0].horizontal_size), int(part[0].vertical_size)
+            buf = np.empty((len(part), h, w, 3), dtype=np.float32)
+            cds = (_abi.CameraDesc * len(part))(*[c.to_desc() for c in part])
+            _abi.check(self.lib.rt355_multi_render_batch(self.handle, cds, len(part), max_depth, buf.ctypes.data,
+                                                         C.byref(stats) if stats is not None else None))
+            out += [Canvas(w, h, buf[f]) for f in range(len(part))]
+        return out
+
     def close(self):
         if self.handle:
             self.lib.rt355_multi_destroy(self.handle)

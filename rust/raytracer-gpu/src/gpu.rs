@@ -148,19 +148,19 @@ impl GpuRenderer {
 impl GpuRenderer {
     /// `Camera::render` for every camera of a path (all of one image size).  The frames go through launch chains
     /// of up to RT355_MAX_BATCH frames whose rays are traced together: a GPU that one 1080p frame leaves half
-    /// idle is filled by four.  (With the multi-GPU backend the frames are rendered one call each.)
+    /// idle is filled by four, and eight GPUs that each render an eighth of a frame by eight frames.
     pub fn render_path(&self, cameras: &[Camera]) -> Result<Vec<Canvas>, String> {
-        let (ctx, scene) = match self.backend {
-            Backend::One { ctx, scene } => (ctx, scene),
-            Backend::Multi(_) => return cameras.iter().map(|c| self.render(c)).collect(),
-        };
         let mut canvases = Vec::with_capacity(cameras.len());
         for part in cameras.chunks(RT355_MAX_BATCH) {
             let cams: Vec<rt355_camera_desc> = part.iter().map(camera_desc).collect();
             let per = cams[0].hsize as usize * cams[0].vsize as usize * 3;
             let mut rgb = vec![0f32; per * cams.len()];
+            let n = cams.len() as i32;
             let rc = unsafe {
-                rt355_render_batch(ctx, scene, cams.as_ptr(), cams.len() as i32, 5, rgb.as_mut_ptr(), ptr::null_mut())
+                match self.backend {
+                    Backend::One { ctx, scene } => rt355_render_batch(ctx, scene, cams.as_ptr(), n, 5, rgb.as_mut_ptr(), ptr::null_mut()),
+                    Backend::Multi(m) => rt355_multi_render_batch(m, cams.as_ptr(), n, 5, rgb.as_mut_ptr(), ptr::null_mut()),
+                }
             };
             if rc != RT355_OK {
                 return Err(last_error());

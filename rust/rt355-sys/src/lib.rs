@@ -160,6 +160,8 @@ extern "C" {
                               light: *const rt355_light_desc) -> c_int;
     pub fn rt355_multi_render(multi: *mut rt355_multi, cam: *const rt355_camera_desc, max_depth: c_int,
                               rgb_out: *mut f32, stats: *mut rt355_stats) -> c_int;
+    pub fn rt355_multi_render_batch(multi: *mut rt355_multi, cams: *const rt355_camera_desc, n_frames: c_int,
+                                    max_depth: c_int, rgb_out: *mut f32, stats: *mut rt355_stats) -> c_int;
     pub fn rt355_multi_gather_kind(multi: *const rt355_multi) -> *const c_char;
     pub fn rt355_color_at(ctx: *mut rt355_ctx, scene: *const rt355_scene, rays: *const f32, n: usize,
                           max_depth: c_int, rgb_out: *mut f32, stats: *mut rt355_stats) -> c_int;

@@ -707,6 +707,16 @@ def test_multi_device_render_from_one_process(real_bits):
                 assert np.array_equal(got, want), ids
             # generation 0 counts tile padding, which depends on the split; the rest must add up exactly
             assert list(st.radiance_rays)[1:] == list(st1.radiance_rays)[1:] and list(st.hits) == list(st1.hits)
+            # a camera path: every device renders its tiles of all the frames in one launch chain (rt355_multi_render_batch)
+            cam2 = Camera(200, 150, math.pi / 3, mx.view_transformation(mx.point(0.6, 1.5, -5.0), mx.point(0, 1, 0), mx.vector(0, 1, 0)))
+            want2 = dev.upload(world)
+            try:
+                w2 = want2.render(cam2, 5).pixels
+            finally:
+                want2.close()
+            path = multi.render_path([cam, cam2, cam], 5)
+            assert [np.array_equal(c.pixels, w_) for c, w_ in zip(path, (want, w2, want))] == [True] * 3, ids
+            assert np.array_equal(multi.render(cam2, 5).pixels, w2)  # a shorter chain after a longer one
             multi.upload(World.new_default())  # a second scene replaces the first on every device
             small = Camera(40, 30, math.pi / 3, mx.view_transformation(mx.point(0, 0, -5), mx.point(0, 0, 0), mx.vector(0, 1, 0)))
             assert np.array_equal(multi.render(small, 5).pixels, small.render(World.new_default(), 5, dev).pixels)
