@@ -160,6 +160,9 @@ class FrameLoop:
         self.launches = 0
         self.frame = 0
         self.stats_frames = 0       # how many frames the statistics of the last finished chain cover
+        self.rays_traced = 0        # radiance + shadow rays of all finished frames (library renders only), tile padding excluded
+        self.frames_done = 0
+        self._active = None         # pixels of a frame this rank owns
 
     def close(self):
         self.flush()
@@ -198,7 +201,14 @@ class FrameLoop:
         nf, n = len(cameras), self.n
         self.pending[k] = None
         if self._custom is None:
-            _abi.check(ctx.lib.rt355_frame_end(ctx.handle, C.byref(stats) if stats is not None else None))  # the tiles are complete
+            if stats is None:
+                stats = _abi.Stats()
+            _abi.check(ctx.lib.rt355_frame_end(ctx.handle, C.byref(stats)))  # the tiles are complete
+            if self._active is None:
+                self._active = int((tile_pixels(self.width, self.height, self.rank, self.world_size) >= 0).sum())
+            # generation 0 counts every slot of the rank's tiles; the slots beyond the image edge hold no ray
+            self.rays_traced += int(stats.total_radiance + stats.total_shadow) - (int(stats.radiance_rays[0]) - nf * self._active)
+        self.frames_done += nf
         self.stats_frames = nf
         if self.direct:
             self.ready.extend(self.canvases[self.where[k]][f] for f in range(nf))

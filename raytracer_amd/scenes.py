@@ -26,6 +26,12 @@ def _camera(w, h, fov, frm, to, up):
     return Camera(w, h, fov, mx.view_transformation(mx.point(*frm), mx.point(*to), mx.vector(*up)))
 
 
+def orbit(camera, angle):
+    """The camera turned by `angle` (radians) about the world's Y axis, everything else kept: one step of a
+    camera path around a scene."""
+    return Camera(camera.horizontal_size, camera.vertical_size, camera.field_of_view, camera.transform @ mx.rotation_y(-angle))
+
+
 def ch9(width=200, height=150):
     """Config 1: src/main.rs:202-273 verbatim (floor plane, two spheres, one light)."""
     floor = Shape.Plane(None, Material(color=(1.0, 0.9, 0.9)))
