@@ -629,6 +629,88 @@ def test_frame_loop_on_one_rank(dev):
         scene.close()
 
 
+def _two_rank_loop_worker(rank, world_size, port, as_u8, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import dist as rd
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)  # both ranks on GPU 0: gloo stages CUDA tensors
+    try:
+        torch.cuda.set_device(0)
+        world, cam0 = scenes.glass(150, 100)
+        cams = [cam0] + [scenes.orbit(cam0, 0.05 * k) for k in range(1, 7)]
+        d = Device(0, 64)
+        scene = d.upload(world)
+        loop = rd.FrameLoop(scene, d, 150, 100, rank, world_size, as_u8=as_u8, in_flight=2, batch=3)
+        outs = []
+        for c in cams:
+            o = loop.step(c)
+            if o is not None:
+                outs.append(o.cpu().numpy().copy())
+        outs += [o.cpu().numpy() for o in loop.flush()]
+        rays = loop.rays_traced
+        loop.close()
+        if rank == 0:
+            wants = [scene.render(c, 5).pixels for c in cams]
+            q.put((outs, wants, rays))
+        else:
+            assert outs == []
+            q.put(rays)
+        scene.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("as_u8", [False, True])
+def test_frame_loop_two_ranks_on_one_gpu(as_u8):
+    """The loop bench.py runs for N > 1, with the library rendering: two processes (both on GPU 0, gloo in place of
+    RCCL) render their tiles of a camera path, three frames per chain and two chains in flight, gather them and
+    un-tile on rank 0.  Every canvas must equal Camera::render of its camera, and the rays the two ranks count
+    must add up to the rays of the whole frames."""
+    import socket
+    import torch.multiprocessing as mp
+    from raytracer_amd.host import Color
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_loop_worker, args=(r, 2, port, as_u8, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    import queue
+    import time
+    got, deadline = [], time.time() + 150
+    while len(got) < 2 and time.time() < deadline:
+        try:
+            got.append(q.get(timeout=2))
+        except queue.Empty:
+            assert all(p.is_alive() or p.exitcode == 0 for p in procs), [p.exitcode for p in procs]  # a rank died: do not wait for it
+    for p in procs:
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+    assert len(got) == 2 and all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    (outs, wants, rays0), rays1 = (got[0], got[1]) if isinstance(got[0], tuple) else (got[1], got[0])
+    assert len(outs) == len(wants) == 7
+    for o, w in zip(outs, wants):
+        assert np.array_equal(o, Color.to_u8(w) if as_u8 else w)
+    world, cam0 = scenes.glass(150, 100)
+    d = Device.get(0, 64)
+    scene = d.upload(world)
+    try:
+        total = 0
+        for c in [cam0] + [scenes.orbit(cam0, 0.05 * k) for k in range(1, 7)]:
+            st = Stats()
+            scene.render(c, 5, st)
+            total += int(st.total_radiance + st.total_shadow) - (int(st.radiance_rays[0]) - 150 * 100)
+    finally:
+        scene.close()
+    assert rays0 + rays1 == total
+
+
 @pytest.mark.parametrize("real_bits", [64, 32])
 def test_batch_of_frames_in_one_launch_chain(real_bits):
     """rt355_render_tiles_batch_begin / rt355_untile_batch: several cameras of one size rendered by ONE launch
