@@ -682,7 +682,7 @@ def test_frame_loop_two_ranks_on_one_gpu(as_u8):
         p.start()
     import queue
     import time
-    got, deadline = [], time.time() + 150
+    got, deadline = [], time.time() + 240
     while len(got) < 2 and time.time() < deadline:
         try:
             got.append(q.get(timeout=2))
