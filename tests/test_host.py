@@ -610,3 +610,23 @@ def test_cpp_host_mirror_cpu_part():
     r = subprocess.run([CPP_TEST, "--cpu", OBJ], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "cpu: 0 failure(s)" in r.stdout
+
+
+def test_orbit_turns_the_camera_about_the_world_y_axis(oracle):
+    """scenes.orbit (the camera path bench.py steps through): angle 0 keeps the camera, and the orbiting camera's
+    rays are the first camera's rays turned about Y (checked with the oracle's ray_for_pixel restatement through a
+    render of a scene that is symmetric about the Y axis: the image does not change)."""
+    from raytracer_amd import scenes
+    from raytracer_amd.host import Material, PointLight, Shape, World
+    world, cam = scenes.ch9(40, 30)
+    same = scenes.orbit(cam, 0.0)
+    assert np.array_equal(same.transform, cam.transform)
+    # a sphere on the Y axis, lit from a point on the Y axis: symmetric under any turn about Y
+    sym = World(PointLight((0.0, 10.0, 0.0), (1, 1, 1)), [Shape.Sphere(mx.translation(0, 1, 0), Material(color=(0.8, 0.3, 0.2)))])
+    a, _, _ = oracle.render(sym, cam, 5, 64)
+    b, _, _ = oracle.render(sym, scenes.orbit(cam, 0.7), 5, 64)
+    assert np.abs(a - b).max() < 1e-5 and a.max() > 0.1
+    # and a scene that is not symmetric does change
+    c, _, _ = oracle.render(world, cam, 5, 64)
+    d, _, _ = oracle.render(world, scenes.orbit(cam, 0.7), 5, 64)
+    assert np.abs(c - d).max() > 0.05
