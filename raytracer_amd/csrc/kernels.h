@@ -291,11 +291,13 @@ RT_FN bool tri_hit(const DevTri& T, V3<R> o, V3<R> d, R& t, R& u, R& v) {
 // Box culling in single precision, conservative.  The boxes only decide which primitives get tested; the
 // tests themselves stay in R.  So the slab arithmetic may run in float, as long as it never reports a
 // miss for a box the exact ray touches.  With P a box plane, exact entry/exit parameters are
-// (P - o) / d.  Here they are evaluated as fma(P, id, c) with id = float(1/d) and c = -float(o/d) -/+ E;
-// the rounding of id, of o/d and of the fma together is below (|P| + |o|) * |id| * 2^-23, and E is twice
-// that with |P| replaced by the largest box coordinate of the scene, subtracted on the near side and added
-// on the far side.  1/d is clamped to +-1e28, so axis-parallel rays stay finite.  The sign of id picks the
-// near plane, so there is no min / max per axis.
+// (P - o) / d.  Here they are evaluated as fma(P, id, c) with id = rcp(float(d)) (the hardware reciprocal, good to
+// one unit in the last place) and c = -(float(o) * id) -/+ E.  Relative to (|P| + |o|) * |id| the errors are: d to
+// float 2^-24, the reciprocal 2^-23, o to float, the product o * id, the fma and the sum c, 2^-24 each: 7 * 2^-24 in
+// all.  E is 2^-20 of that quantity with |P| replaced by the largest box coordinate of the scene, subtracted on the
+// near side and added on the far side.  1/d is clamped to +-1e28, so axis-parallel rays stay finite.  The sign of
+// id picks the near plane, so there is no min / max per axis.  (A reciprocal and a product in double, rounded
+// afterwards, would allow a tighter E; they cost three double-precision divisions per ray and per traversal.)
 // ------------------------------------------------------------------------------------------------
 struct SlabRay {
   float ix, iy, iz;  // 1 / d
@@ -306,13 +308,13 @@ template <class R>
 RT_FN SlabRay make_slab_ray(V3<R> o, V3<R> d, float abs_max) {
   SlabRay s;
   auto axis = [&](R oc, R dc, float& i, float& n, float& f) {
-    double id = 1.0 / (double)dc;
-    if (!(fabs(id) < 1e28)) id = copysign(1e28, (double)dc);
-    const double oid = (double)oc * id;
-    i = (float)id;
-    const float e = (abs_max + fabsf((float)oc) * 1.0000002f) * fabsf(i) * 2.3841858e-7f;  // 2^-22
-    n = -(float)oid - e;
-    f = -(float)oid + e;
+    const float df = (float)dc, of = (float)oc;
+    i = __builtin_amdgcn_rcpf(df);
+    if (!(fabsf(i) < 1e28f)) i = copysignf(1e28f, df);
+    const float oi = of * i;
+    const float e = (abs_max + fabsf(of) * 1.0000002f) * fabsf(i) * 9.5367432e-7f;  // 2^-20
+    n = -oi - e;
+    f = -oi + e;
   };
   axis(o.x, d.x, s.ix, s.nx, s.fx);
   axis(o.y, d.y, s.iy, s.ny, s.fy);
