@@ -446,6 +446,8 @@ RT_FN DevTri load_tri_uniform(const DevScene<R>& sc, int p) {
   return T;
 }
 
+constexpr int PACKET_LEAF_GROUP = 2;  // triangle records of a leaf the packet traversal holds at a time
+
 template <class R, bool COUNT, class Vis>
 RT_FN void traverse_packet(const DevScene<R>& sc, V3<R> o, V3<R> d, bool live, Vis& vis, Work& wk, int* wstack) {
   for (int p = sc.n_bounded; p < sc.n_prims; ++p)
@@ -503,15 +505,22 @@ RT_FN void traverse_packet(const DevScene<R>& sc, V3<R> o, V3<R> d, bool live, V
       const uint32_t leaf = (uint32_t)~cur;
       const int first = (int)(leaf & LEAF_FIRST_MASK), count = (int)(leaf >> 26);
       if (leaf & LEAF_TRI_BIT) {
-        DevTri T[LEAF_MAX];
+        // two records at a time: four would hold 48 scalar registers at once, and the packet kernels are short of
+        // scalar registers (what does not fit is parked in vector lanes and fetched back every trip); measured 3 %
+        // of the frame against one more dependent scalar load per leaf of three or four triangles
 #pragma unroll
-        for (int k = 0; k < LEAF_MAX; ++k) T[k] = load_tri_uniform(sc, first + (k < count ? k : 0));
+        for (int h = 0; h < LEAF_MAX; h += PACKET_LEAF_GROUP) {
+          if (h >= count) break;
+          DevTri T[PACKET_LEAF_GROUP];
 #pragma unroll
-        for (int k = 0; k < LEAF_MAX; ++k)
-          if (k < count && live) {
-            if constexpr (COUNT) wk.prim[T[k].flags & PF_KIND_MASK]++;
-            if (vis.tri(first + k, T[k])) live = false;
-          }
+          for (int k = 0; k < PACKET_LEAF_GROUP; ++k) T[k] = load_tri_uniform(sc, first + (h + k < count ? h + k : 0));
+#pragma unroll
+          for (int k = 0; k < PACKET_LEAF_GROUP; ++k)
+            if (h + k < count && live) {
+              if constexpr (COUNT) wk.prim[T[k].flags & PF_KIND_MASK]++;
+              if (vis.tri(first + h + k, T[k])) live = false;
+            }
+        }
         for (int k = LEAF_MAX; k < count; ++k) {
           const DevTri Tk = load_tri_uniform(sc, first + k);
           if (live) {
