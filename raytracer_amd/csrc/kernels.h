@@ -133,20 +133,40 @@ template <bool COUNT> RT_FN void flush_work(FrameCtl* ctl, int launch, const Wor
   }
 }
 
+// A record every lane of the wave reads at the same address: through the scalar cache into scalar registers, one
+// request per wave and a far shorter latency than 64 identical vector loads.
+template <class T> using cptr = const __attribute__((address_space(4))) T*;
+template <class T>
+RT_FN T load_uniform(const T* p) {
+  static_assert(sizeof(T) % 4 == 0, "whole dwords");
+  T out;
+  cptr<uint32_t> q = (cptr<uint32_t>)(const uint32_t*)p;
+  uint32_t* o = (uint32_t*)&out;
+#pragma unroll
+  for (size_t i = 0; i < sizeof(T) / 4; ++i) o[i] = q[i];
+  return out;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Shape::intersect = local_intersect(ray.inv_transform(transformation))  (src/shape.rs:208-415)
 // emit(t, u, v, emission_index) is called once per intersection, in the reference's emission order.
 // ------------------------------------------------------------------------------------------------
-template <class R, bool COUNT, class Emit>
+// UNIFORM: p is the same in every lane of the wave (the every-ray list, the leaves of a packet traversal).
+template <class R, bool COUNT, bool UNIFORM = false, class Emit>
 RT_FN void prim_hits(const DevScene<R>& sc, int p, int flags, V3<R> wo, V3<R> wd, Work& wk, Emit&& emit) {
   const int kind = flags & PF_KIND_MASK;
   if constexpr (COUNT) wk.prim[kind]++;
   V3<R> o = wo, d = wd;
-  if (!(flags & PF_IDENTITY)) {
-    const R* r = sc.xform[p].r;
-    o = xf_point(r, wo);
-    d = xf_vec(r, wd);
-    if constexpr (COUNT) wk.xf++;
+  R ext_min = R(0), ext_max = R(0);
+  if (!(flags & PF_IDENTITY) || kind == RT355_CYLINDER || kind == RT355_CONE) {
+    DevXform<R> X;
+    if constexpr (UNIFORM) X = load_uniform(&sc.xform[p]); else X = sc.xform[p];
+    ext_min = X.ymin, ext_max = X.ymax;
+    if (!(flags & PF_IDENTITY)) {
+      o = xf_point(X.r, wo);
+      d = xf_vec(X.r, wd);
+      if constexpr (COUNT) wk.xf++;
+    }
   }
   const R EPS = eps<R>();
   if (kind >= RT355_TRIANGLE) {
@@ -192,7 +212,7 @@ RT_FN void prim_hits(const DevScene<R>& sc, int p, int flags, V3<R> wo, V3<R> wd
     }
     case RT355_CYLINDER:
     case RT355_CONE: {  // src/shape.rs:249-327, caps 468-514
-      const R ymin = sc.xform[p].ymin, ymax = sc.xform[p].ymax;
+      const R ymin = ext_min, ymax = ext_max;
       const bool cone = kind == RT355_CONE;
       int em = 0;
       if (!cone) {
@@ -257,12 +277,14 @@ RT_FN bool tri_hit(const DevTri& T, V3<R> o, V3<R> d, R& t, R& u, R& v) {
 #ifdef RT355_EXP_NO_TRI
   return false;  // timing experiment only: what the frame costs without any triangle arithmetic
 #endif
+  // Straight-line code with two wave-level exits: every lane evaluates the same expressions and carries a
+  // predicate; the wave leaves early when no lane of it can still hit.  (Per-lane early returns cost an exec-mask
+  // save / restore and a set of register copies at every exit, more than the arithmetic they skip.)
   const V3<R> p1 = {R(T.p1[0]), R(T.p1[1]), R(T.p1[2])};
   const V3<R> e1 = {R(T.p2[0]) - p1.x, R(T.p2[1]) - p1.y, R(T.p2[2]) - p1.z};  // src/triangle.rs:83
   const V3<R> e2 = {R(T.p3[0]) - p1.x, R(T.p3[1]) - p1.y, R(T.p3[2]) - p1.z};  // src/triangle.rs:84
   const V3<R> dir_cross_e2 = cross(d, e2);
   const R det = dot(e1, dir_cross_e2);
-  if (approx_zero(fabs(det))) return false;
   const V3<R> p1_to_origin = o - p1;
   // The reference divides first (f = 1/det) and then tests u = f*un, v = f*vn.  Most tests miss, and a
   // miss can be told without the division: u < 0 exactly when un and det differ in sign, and u > 1
@@ -273,18 +295,21 @@ RT_FN bool tri_hit(const DevTri& T, V3<R> o, V3<R> d, R& t, R& u, R& v) {
   const R tiny = adet * (R(16) * std::numeric_limits<R>::min());
   const R un = dot(p1_to_origin, dir_cross_e2);
   const R aun = fabs(un);
-  if (aun > tiny && (((un < R(0)) != (det < R(0))) || aun > slack)) return false;
+  // (bitwise operators on purpose: no short-circuit evaluation, hence no branches around single compares)
+  const bool det_neg = det < R(0);
+  bool maybe = !approx_zero(adet);
+  maybe = maybe & !((aun > tiny) & (((un < R(0)) != det_neg) | (aun > slack)));
+  if (__builtin_amdgcn_ballot_w64(maybe) == 0ull) return false;
   const V3<R> origin_cross_e1 = cross(p1_to_origin, e1);
   const R vn = dot(d, origin_cross_e1);
   const R avn = fabs(vn);
-  if (avn > tiny && (((vn < R(0)) != (det < R(0))) || (aun > tiny && aun + avn > slack))) return false;
+  maybe = maybe & !((avn > tiny) & (((vn < R(0)) != det_neg) | ((aun > tiny) & (aun + avn > slack))));
+  if (__builtin_amdgcn_ballot_w64(maybe) == 0ull) return false;
   const R f = R(1) / det;
   u = f * un;
-  if (u < R(0) || u > R(1)) return false;
   v = f * vn;
-  if (v < R(0) || (u + v) > R(1)) return false;
   t = f * dot(e2, origin_cross_e1);
-  return true;
+  return maybe & !((u < R(0)) | (u > R(1))) & !((v < R(0)) | ((u + v) > R(1)));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -311,6 +336,7 @@ RT_FN SlabRay make_slab_ray(V3<R> o, V3<R> d, float abs_max) {
     const float df = (float)dc, of = (float)oc;
     i = __builtin_amdgcn_rcpf(df);
     if (!(fabsf(i) < 1e28f)) i = copysignf(1e28f, df);
+    if (fabsf(i) < 1e-30f) i = copysignf(1e-30f, df);  // never zero: an infinite plane times i stays infinite
     const float oi = of * i;
     const float e = (abs_max + fabsf(of) * 1.0000002f) * fabsf(i) * 9.5367432e-7f;  // 2^-20
     n = -oi - e;
@@ -326,7 +352,7 @@ template <class R>
 RT_FN void slab_interval(R tmin, R tmax, float& lo, float& hi) {
   const float a = (float)tmin, b = (float)tmax;
   lo = a - fabsf(a) * 1.1920929e-7f;
-  hi = b + fabsf(b) * 1.1920929e-7f;
+  hi = fminf(b + fabsf(b) * 1.1920929e-7f, 3.4028235e38f);  // finite: an empty child slot (x planes at +inf) then never passes
 }
 // true when the ray may touch the box within [tlo, thi]; tn = (conservative) entry parameter
 RT_FN bool slab_test(const SlabRay& s, float lox, float loy, float loz, float hix, float hiy, float hiz, float tlo, float thi, float& tn) {
@@ -349,7 +375,7 @@ RT_FN bool slab_test(const SlabRay& s, float lox, float loy, float loz, float hi
 template <class R, bool COUNT, class Vis>
 RT_FN void traverse(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work& wk, int* lds) {
   for (int p = sc.n_bounded; p < sc.n_prims; ++p)
-    if (vis.prim(p)) return;
+    if (vis.prim_u(p)) return;
   if (sc.n_nodes == 0) return;
   const SlabRay sr = make_slab_ray(o, d, sc.box_abs_max);
   int spill[STACK_DEPTH - LDS_STACK];
@@ -371,10 +397,10 @@ RT_FN void traverse(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work& wk,
       slab_interval(vis.tmin(), vis.tmax(), tlo, thi);
       // entry parameter of every child the ray may touch, +inf for the others
       float k0, k1, k2, k3;
-      if (!slab_test(sr, N.box[0][0], N.box[0][1], N.box[0][2], N.box[0][3], N.box[0][4], N.box[0][5], tlo, thi, k0)) k0 = INFINITY;
-      if (!slab_test(sr, N.box[1][0], N.box[1][1], N.box[1][2], N.box[1][3], N.box[1][4], N.box[1][5], tlo, thi, k1)) k1 = INFINITY;
-      if (!slab_test(sr, N.box[2][0], N.box[2][1], N.box[2][2], N.box[2][3], N.box[2][4], N.box[2][5], tlo, thi, k2)) k2 = INFINITY;
-      if (!slab_test(sr, N.box[3][0], N.box[3][1], N.box[3][2], N.box[3][3], N.box[3][4], N.box[3][5], tlo, thi, k3)) k3 = INFINITY;
+      if (!slab_test(sr, N.box[0][0], N.box[0][2], N.box[0][4], N.box[0][1], N.box[0][3], N.box[0][5], tlo, thi, k0)) k0 = INFINITY;
+      if (!slab_test(sr, N.box[1][0], N.box[1][2], N.box[1][4], N.box[1][1], N.box[1][3], N.box[1][5], tlo, thi, k1)) k1 = INFINITY;
+      if (!slab_test(sr, N.box[2][0], N.box[2][2], N.box[2][4], N.box[2][1], N.box[2][3], N.box[2][5], tlo, thi, k2)) k2 = INFINITY;
+      if (!slab_test(sr, N.box[3][0], N.box[3][2], N.box[3][4], N.box[3][1], N.box[3][3], N.box[3][5], tlo, thi, k3)) k3 = INFINITY;
       int c0 = N.c[0], c1 = N.c[1], c2 = N.c[2], c3 = N.c[3];
       if constexpr (COUNT) wk.box += (c0 != -1) + (c1 != -1) + (c2 != -1) + (c3 != -1);
       // nearest first: 5-exchange sorting network on (entry, child)
@@ -433,8 +459,6 @@ RT_FN void traverse(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work& wk,
 // mirror reflections); incoherent generations use the per-lane traverse above.
 // All 64 lanes must call this together; `live` is false for lanes without a ray.
 // ------------------------------------------------------------------------------------------------
-template <class T> using cptr = const __attribute__((address_space(4))) T*;
-
 template <class R>
 RT_FN DevTri load_tri_uniform(const DevScene<R>& sc, int p) {
   DevTri T;
@@ -448,16 +472,59 @@ RT_FN DevTri load_tri_uniform(const DevScene<R>& sc, int p) {
 
 constexpr int PACKET_LEAF_GROUP = 2;  // triangle records of a leaf the packet traversal holds at a time
 
+// The slab constants of a packet's ray.  Per axis the two planes of a box give a = fma(lo, i, ca) and
+// b = fma(hi, i, cb) with ca = -(o * i) - e * sign(i), cb = -(o * i) + e * sign(i): whichever of the two is the
+// near plane for this lane's direction carries -e and the other +e, so min(a, b) is the conservative entry and
+// max(a, b) the conservative exit of the axis without a select per plane.  (lo, hi) sit side by side in the node
+// and (ca, cb) side by side here: one packed instruction evaluates both.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct SlabRayP {
+  float ix, iy, iz;
+  f32x2 cx, cy, cz;  // (ca, cb) per axis
+};
+RT_FN SlabRayP make_slab_ray_p(const SlabRay& s) {
+  SlabRayP r;
+  r.ix = s.ix, r.iy = s.iy, r.iz = s.iz;
+  r.cx = s.ix >= 0.f ? f32x2{s.nx, s.fx} : f32x2{s.fx, s.nx};
+  r.cy = s.iy >= 0.f ? f32x2{s.ny, s.fy} : f32x2{s.fy, s.ny};
+  r.cz = s.iz >= 0.f ? f32x2{s.nz, s.fz} : f32x2{s.fz, s.nz};
+  return r;
+}
+// One box against the lane's ray: true when the ray may touch it within [tlo, thi]; tn = conservative entry, >= tlo.
+// An empty child slot has both its x planes at +inf: entry and exit of that axis are then +inf or -inf together and
+// the test fails for every finite [tlo, thi].
+RT_FN bool slab_test_p(const SlabRayP& s, f32x2 bx, f32x2 by, f32x2 bz, float tlo, float thi, float& tn) {
+  const f32x2 tx = __builtin_elementwise_fma(bx, f32x2{s.ix, s.ix}, s.cx);
+  const f32x2 ty = __builtin_elementwise_fma(by, f32x2{s.iy, s.iy}, s.cy);
+  const f32x2 tz = __builtin_elementwise_fma(bz, f32x2{s.iz, s.iz}, s.cz);
+  tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), tlo));
+  const float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), thi));
+  return tn <= tf;
+}
+
 template <class R, bool COUNT, class Vis>
-RT_FN void traverse_packet(const DevScene<R>& sc, V3<R> o, V3<R> d, bool live, Vis& vis, Work& wk, int* wstack) {
+RT_FN void traverse_packet(const DevScene<R>& sc, V3<R> o, V3<R> d, bool live, Vis& vis, Work& wk, int* /*unused*/) {
   for (int p = sc.n_bounded; p < sc.n_prims; ++p)
-    if (live && vis.prim(p)) live = false;
+    if (live && vis.prim_u(p)) live = false;
   if (sc.n_nodes == 0) return;
-  const SlabRay sr = make_slab_ray(o, d, sc.box_abs_max);
+  const SlabRayP sr = make_slab_ray_p(make_slab_ray(o, d, sc.box_abs_max));
+  // every visitor's lower bound is fixed for the length of a traversal
+  float tlo;
+  {
+    const float a = (float)vis.tmin();
+    tlo = a - fabsf(a) * 1.1920929e-7f;
+  }
+  // The stack is ONE vector register: slot k lives in lane k (STACK_DEPTH == 64 lanes), pushed with a compare and a
+  // select against the lane number and popped with v_readlane from a scalar stack pointer -- no LDS round trip
+  // between a leaf and the next node.
+  static_assert(STACK_DEPTH == 64, "the packet stack is one lane per slot");
+  const int lane_id = (int)(threadIdx.x & 63u);
+  int stackv = 0;
   int sp = 0;
   int cur = 0;
   for (;;) {
-    if (__ballot(live) == 0ull) return;
+    const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(live);
+    if (live_mask == 0ull) return;
 #ifdef RT355_EXP_STAMPS
     DbgAcc& dacc = wk.dbg;
     const unsigned long long dc0 = __builtin_amdgcn_s_memtime();
@@ -466,27 +533,34 @@ RT_FN void traverse_packet(const DevScene<R>& sc, V3<R> o, V3<R> d, bool live, V
     struct Closer { DbgAcc& a; unsigned long long c0; bool n, t, p; RT_FN ~Closer() { const unsigned long long dt = __builtin_amdgcn_s_memtime() - c0; if (n) a.cyc_node += dt; if (t) a.cyc_tri += dt; if (p) a.cyc_prim += dt; } } closer{dacc, dc0, d_node, d_tri, d_prim};
 #endif
     if (cur >= 0) {
-      cptr<float> q = (cptr<float>)(const float*)&sc.nodes[cur].box[0][0];
+      // the whole node through scalar loads issued together: one wait per node
+      cptr<f32x2> q = (cptr<f32x2>)(const f32x2*)&sc.nodes[cur].box[0][0];
       cptr<int32_t> qc = (cptr<int32_t>)(const int32_t*)&sc.nodes[cur].c[0];
-      float tlo, thi;
-      slab_interval(vis.tmin(), vis.tmax(), tlo, thi);
+      f32x2 B[BVH_WIDTH][3];
+      int ch[BVH_WIDTH];
+#pragma unroll
+      for (int k = 0; k < BVH_WIDTH; ++k) B[k][0] = q[3 * k], B[k][1] = q[3 * k + 1], B[k][2] = q[3 * k + 2], ch[k] = qc[k];
+      float thi;
+      {
+        const float b = (float)vis.tmax();
+        thi = fminf(b + fabsf(b) * 1.1920929e-7f, 3.4028235e38f);
+      }
       // A child is entered when any live lane may touch it.  Order: by the entry parameter of the first
       // lane that touches the child (a scalar, so the sort runs on the scalar unit).
       uint32_t key[BVH_WIDTH];
-      int ch[BVH_WIDTH];
       int n_valid = 0;
 #pragma unroll
       for (int k = 0; k < BVH_WIDTH; ++k) {
         float tn;
-        const bool h = slab_test(sr, q[6 * k], q[6 * k + 1], q[6 * k + 2], q[6 * k + 3], q[6 * k + 4], q[6 * k + 5], tlo, thi, tn) && live;
-        const unsigned long long m = __ballot(h);
-        ch[k] = qc[k];
-        n_valid += ch[k] != -1;
-        key[k] = 0xFFFFFFFFu;
-        if (m) {
-          const int lane = __ffsll((long long)m) - 1;
-          key[k] = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(fmaxf(tn, 0.f)), lane);
-        }
+        // the compare's own lane mask, narrowed to the live lanes on the scalar unit
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(slab_test_p(sr, B[k][0], B[k][1], B[k][2], tlo, thi, tn)) & live_mask;
+        if constexpr (COUNT) n_valid += ch[k] != -1;
+        // entry parameter of the first lane that touches the child; with no such lane the scalar bit search yields -1,
+        // the lane read is then any lane's and the key is discarded.  Negative entries (visitors whose interval starts
+        // below zero) order as zero.
+        const int lane = __builtin_ffsll((long long)m) - 1;
+        const int bits = __builtin_amdgcn_readlane((int)__float_as_uint(tn), lane);
+        key[k] = m ? (uint32_t)(bits < 0 ? 0 : bits) : 0xFFFFFFFFu;
       }
       if constexpr (COUNT) wk.box += live ? n_valid : 0;
       auto order = [](uint32_t& ka, int& ca, uint32_t& kb, int& cb) {
@@ -497,10 +571,19 @@ RT_FN void traverse_packet(const DevScene<R>& sc, V3<R> o, V3<R> d, bool live, V
       };
       order(key[0], ch[0], key[1], ch[1]), order(key[2], ch[2], key[3], ch[3]), order(key[0], ch[0], key[2], ch[2]);
       order(key[1], ch[1], key[3], ch[3]), order(key[1], ch[1], key[2], ch[2]);
-      if (key[3] != 0xFFFFFFFFu) wstack[sp++] = ch[3];
-      if (key[2] != 0xFFFFFFFFu) wstack[sp++] = ch[2];
-      if (key[1] != 0xFFFFFFFFu) wstack[sp++] = ch[1];
-      if (key[0] != 0xFFFFFFFFu) { cur = ch[0]; continue; }
+      // the touched children come first, nearest in ch[0]: that one is entered, the others go on the stack, farthest lowest
+      const uint32_t INV = 0xFFFFFFFFu;
+      const int nv = key[3] != INV ? 4 : key[2] != INV ? 3 : key[1] != INV ? 2 : key[0] != INV ? 1 : 0;  // touched children
+#pragma unroll
+      for (int j = 1; j < BVH_WIDTH; ++j) {
+        const int slot = nv > j ? sp + nv - 1 - j : -1;  // scalar; -1 is no lane's number
+        stackv = lane_id == slot ? ch[j] : stackv;
+      }
+      sp += (nv > 1 ? nv : 1) - 1;
+      if (nv > 0) {
+        cur = ch[0];
+        continue;
+      }
     } else {
       const uint32_t leaf = (uint32_t)~cur;
       const int first = (int)(leaf & LEAF_FIRST_MASK), count = (int)(leaf >> 26);
@@ -516,25 +599,23 @@ RT_FN void traverse_packet(const DevScene<R>& sc, V3<R> o, V3<R> d, bool live, V
           for (int k = 0; k < PACKET_LEAF_GROUP; ++k) T[k] = load_tri_uniform(sc, first + (h + k < count ? h + k : 0));
 #pragma unroll
           for (int k = 0; k < PACKET_LEAF_GROUP; ++k)
-            if (h + k < count && live) {
-              if constexpr (COUNT) wk.prim[T[k].flags & PF_KIND_MASK]++;
-              if (vis.tri(first + h + k, T[k])) live = false;
+            if (h + k < count) {  // wave-uniform; lanes without a ray run along, the visitor ignores them
+              if constexpr (COUNT) wk.prim[T[k].flags & PF_KIND_MASK] += live ? 1 : 0;
+              live = live & !vis.tri_masked(first + h + k, T[k], live);
             }
         }
         for (int k = LEAF_MAX; k < count; ++k) {
           const DevTri Tk = load_tri_uniform(sc, first + k);
-          if (live) {
-            if constexpr (COUNT) wk.prim[Tk.flags & PF_KIND_MASK]++;
-            if (vis.tri(first + k, Tk)) live = false;
-          }
+          if constexpr (COUNT) wk.prim[Tk.flags & PF_KIND_MASK] += live ? 1 : 0;
+          live = live & !vis.tri_masked(first + k, Tk, live);
         }
       } else {
         for (int k = 0; k < count; ++k)
-          if (live && vis.prim(first + k)) live = false;
+          if (live && vis.prim_u(first + k)) live = false;
       }
     }
     if (sp == 0) return;
-    cur = __builtin_amdgcn_readfirstlane(wstack[--sp]);
+    cur = __builtin_amdgcn_readlane(stackv, --sp);
   }
 }
 
@@ -585,7 +666,7 @@ RT_FN void traverse_quad(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work
   for (;;) {
     if (cur >= 0) {
       const float* b = sc.nodes[cur].box[ql];
-      const float lox = b[0], loy = b[1], loz = b[2], hix = b[3], hiy = b[4], hiz = b[5];
+      const float lox = b[0], hix = b[1], loy = b[2], hiy = b[3], loz = b[4], hiz = b[5];
       const int child = sc.nodes[cur].c[ql];
       if constexpr (COUNT) wk.box += child != -1;
       float tn;
@@ -645,14 +726,34 @@ struct ClosestVis {
   RT_FN void accept(R t, R u, R v, int p, int shape, int flags) {
     if (t >= R(0) && (t < best_t || (t == best_t && shape < best_s))) best_t = t, best_u = u, best_v = v, best_p = p, best_s = shape, best_flags = flags;
   }
+  // the same as selects: for callers that run every lane through the same straight-line code
+  RT_FN void accept_if(bool hit, R t, R u, R v, int p, int shape, int flags) {
+    const bool better = hit & (t >= R(0)) & ((t < best_t) | ((t == best_t) & (shape < best_s)));
+    best_t = better ? t : best_t, best_u = better ? u : best_u, best_v = better ? v : best_v;
+    best_p = better ? p : best_p, best_s = better ? shape : best_s, best_flags = better ? flags : best_flags;
+  }
   RT_FN bool prim(int p) {
     const PrimInfo info = sc.prim_info[p];
     prim_hits<R, COUNT>(sc, p, info.flags, o, d, wk, [&](R t, R u, R v, int) { accept(t, u, v, p, info.shape, info.flags); });
     return false;
   }
+  // p is the same in every lane of the wave
+  RT_FN bool prim_u(int p) {
+    const PrimInfo info = load_uniform(&sc.prim_info[p]);
+    prim_hits<R, COUNT, true>(sc, p, info.flags, o, d, wk, [&](R t, R u, R v, int) { accept(t, u, v, p, info.shape, info.flags); });
+    return false;
+  }
   RT_FN bool tri(int p, const DevTri& T) {
-    R t, u, v;
-    if (tri_hit(T, o, d, t, u, v)) accept(t, u, v, p, T.shape, T.flags);
+    R t = R(0), u = R(0), v = R(0);
+    const bool hit = tri_hit(T, o, d, t, u, v);
+    accept_if(hit, t, u, v, p, T.shape, T.flags);
+    return false;
+  }
+  // for the packet traversal: every lane of the wave calls, `on` marks the lanes that have a ray
+  RT_FN bool tri_masked(int p, const DevTri& T, bool on) {
+    R t = R(0), u = R(0), v = R(0);
+    const bool hit = tri_hit(T, o, d, t, u, v);
+    accept_if(hit & on, t, u, v, p, T.shape, T.flags);
     return false;
   }
   // After a quad traversal: true in the ONE lane of the quad whose own result is the quad's nearest hit by
@@ -694,9 +795,23 @@ struct AnyVis {
     });
     return found;
   }
+  RT_FN bool prim_u(int p) {
+    const PrimInfo info = load_uniform(&sc.prim_info[p]);
+    prim_hits<R, COUNT, true>(sc, p, info.flags, o, d, wk, [&](R t, R, R, int) {
+      if (t >= R(0) && t < limit) found = true;
+    });
+    return found;
+  }
   RT_FN bool tri(int, const DevTri& T) {
-    R t, u, v;
-    if (tri_hit(T, o, d, t, u, v) && t >= R(0) && t < limit) found = true;
+    R t = R(0), u, v;
+    const bool hit = tri_hit(T, o, d, t, u, v);
+    found = found | (hit & (t >= R(0)) & (t < limit));
+    return found;
+  }
+  RT_FN bool tri_masked(int, const DevTri& T, bool on) {
+    R t = R(0), u, v;
+    const bool hit = tri_hit(T, o, d, t, u, v);
+    found = found | (on & hit & (t >= R(0)) & (t < limit));
     return found;
   }
 };
@@ -741,10 +856,22 @@ struct BackwardVis {
     prim_hits<R, COUNT>(sc, p, info.flags, o, d, wk, [&](R tr, R, R, int) { accept(tr, p, info.shape, info.flags); });
     return false;
   }
+  RT_FN bool prim_u(int p) {
+    if (p == p_hit) return false;
+    const PrimInfo info = load_uniform(&sc.prim_info[p]);
+    prim_hits<R, COUNT, true>(sc, p, info.flags, o, d, wk, [&](R tr, R, R, int) { accept(tr, p, info.shape, info.flags); });
+    return false;
+  }
   RT_FN bool tri(int p, const DevTri& T) {
     if (p == p_hit) return false;
     R tr, u, v;
     if (tri_hit(T, o, d, tr, u, v)) accept(tr, p, T.shape, T.flags);
+    return false;
+  }
+  RT_FN bool tri_masked(int p, const DevTri& T, bool on) {
+    R tr = R(0), u, v;
+    const bool hit = tri_hit(T, o, d, tr, u, v);
+    if (on & hit & (p != p_hit)) accept(tr, p, T.shape, T.flags);
     return false;
   }
 };
@@ -889,56 +1016,47 @@ RT_FN void trace_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* 
     if (__ballot(hit) != 0ull) shade_surface<R, COUNT, PACKET>(sc, pool, r, hit, hit ? vis.best_p : 0, lds, wk);
     if (valid && !hit) st3(pool.color + 3ull * r, V3<R>{R(0), R(0), R(0)});  // src/world.rs:61-63: a miss is black
   }
-  wh = __popcll(__ballot(hit)), wc = wave_sum(n_child);
+  // children of the wave's hits: a reflected ray per reflective hit, a refracted one per transparent hit
+  wh = __popcll(__builtin_amdgcn_ballot_w64(hit)), wc = __popcll(__builtin_amdgcn_ballot_w64((n_child & 1u) != 0)) + 2u * __popcll(__builtin_amdgcn_ballot_w64((n_child & 2u) != 0));
 }
 
-// k_trace: trace_chunk over generation `gen`, one chunk per block and trip.  Leaves, per chunk, the hit count
-// and the child bound for k_scan; with `count_hits` set it adds the hits to the generation's total itself
-// (no k_scan launch follows: the frame runs the fused kernels and this is its deepest generation).
+// k_trace: trace_chunk over generation `gen`, one chunk per block and trip.  Every wave leaves the hit count and the
+// child bound of its own 64 rays for k_scan (entry i / 64 of blk_hits / blk_children): no wave waits for another.
 template <class R, bool COUNT, bool PACKET, bool LAST>
-__global__ void __launch_bounds__(256, PACKET ? (LAST ? RT355_WPS_PACKET_LAST : RT355_WPS_PACKET) : RT355_WPS_LANE) k_trace(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch, DevCamera<R> cam, int primary, int count_hits) {
-  __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
-  int* lds = PACKET ? lds_stack + (threadIdx.x >> 6) * STACK_DEPTH : lds_stack + threadIdx.x;
+__global__ void __launch_bounds__(BLOCK, PACKET ? (LAST ? RT355_WPS_PACKET_LAST : RT355_WPS_PACKET) : RT355_WPS_LANE) k_trace(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch, DevCamera<R> cam, int primary) {
+  __shared__ int lds_stack[PACKET ? 1 : LDS_STACK * BLOCK];
+  int* lds = lds_stack + (PACKET ? 0 : threadIdx.x);
   uint32_t start, count;
   gen_range(ctl, gen, pool.capacity, start, count);
-  __shared__ uint32_t s_red[2 * (BLOCK / 64)];
   Work wk;
-  // one ray per lane per trip; the trip count is block-uniform, so all 64 lanes stay converged for the
+  // one ray per lane per trip; the trip count is the same for the 64 lanes of a wave, so they stay converged for the
   // ballots of the packet traversal
   for (uint32_t base = blockIdx.x * BLOCK; base < count; base += gridDim.x * BLOCK) {
     uint32_t wh, wc;
     trace_chunk<R, COUNT, PACKET, LAST>(sc, pool, ctl, cam, primary, start, count, base, remaining, launch, lds, wk, wh, wc);
-    if ((threadIdx.x & 63u) == 0) s_red[threadIdx.x >> 6] = wh, s_red[BLOCK / 64 + (threadIdx.x >> 6)] = wc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t th = 0, tc = 0;
-      for (int w = 0; w < BLOCK / 64; ++w) th += s_red[w], tc += s_red[BLOCK / 64 + w];
-      if (count_hits) {
-        if (th) atomicAdd(&ctl->hit_count[gen].v, th);
-      } else {
-        pool.blk_hits[base / BLOCK] = th;
-        pool.blk_children[base / BLOCK] = tc;
-      }
+    if ((threadIdx.x & 63u) == 0 && base + threadIdx.x < count) {
+      const uint32_t e = (base + threadIdx.x) / GROUP;
+      pool.blk_hits[e] = wh;
+      pool.blk_children[e] = wc;
     }
-    __syncthreads();
   }
   flush_work<COUNT>(ctl, launch, wk);
 }
 
-// k_trace with the quad traversal: a block of 256 threads takes 256 rays per trip, 64 at a time, four lanes
-// to a ray.  Same outputs as k_trace (hit records, per-256-ray hit and child counts for k_scan).
+// k_trace with the quad traversal: a wave takes 64 consecutive rays per trip, 16 at a time, four lanes to a ray.
+// Same outputs as k_trace (hit records, per-wave hit and child counts for k_scan).
 template <class R, bool COUNT>
-__global__ void __launch_bounds__(256, 4) k_trace_q(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch, DevCamera<R> cam, int primary) {
+__global__ void __launch_bounds__(BLOCK, 4) k_trace_q(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch, DevCamera<R> cam, int primary) {
   __shared__ int lds_stack[QUADS * STACK_DEPTH];
   int* stack = lds_stack + (threadIdx.x >> 2);
-  __shared__ uint32_t s_red[2 * (BLOCK / 64)];
   uint32_t start, count;
   gen_range(ctl, gen, pool.capacity, start, count);
   Work wk;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   for (uint32_t base = blockIdx.x * BLOCK; base < count; base += gridDim.x * BLOCK) {
     uint32_t wh = 0, wc = 0;  // this wave's hits and child-ray bound over the four passes
     for (int sub = 0; sub < 4; ++sub) {
-      const uint32_t i = base + sub * QUADS + (threadIdx.x >> 2);
+      const uint32_t i = base + wave * 64u + (uint32_t)sub * 16u + (lane >> 2);
       const bool valid = i < count;
       const uint32_t r = start + (valid ? i : 0u);
       const bool writer = (threadIdx.x & 3u) == 0;
@@ -970,15 +1088,11 @@ __global__ void __launch_bounds__(256, 4) k_trace_q(DevScene<R> sc, RayPool<R> p
       wh += __popcll(__ballot(hit));
       wc += __popcll(__ballot(spawns && (vis.best_flags & PF_REFLECTIVE))) + __popcll(__ballot(spawns && (vis.best_flags & PF_TRANSPARENT)));
     }
-    if ((threadIdx.x & 63u) == 0) s_red[threadIdx.x >> 6] = wh, s_red[BLOCK / 64 + (threadIdx.x >> 6)] = wc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t th = 0, tc = 0;
-      for (int w = 0; w < BLOCK / 64; ++w) th += s_red[w], tc += s_red[BLOCK / 64 + w];
-      pool.blk_hits[base / BLOCK] = th;
-      pool.blk_children[base / BLOCK] = tc;
+    if (lane == 0 && base + wave * 64u < count) {
+      const uint32_t e = (base + wave * 64u) / GROUP;
+      pool.blk_hits[e] = wh;
+      pool.blk_children[e] = wc;
     }
-    __syncthreads();
   }
   flush_work<COUNT>(ctl, launch, wk);
 }
@@ -993,39 +1107,102 @@ __global__ void __launch_bounds__(256) k_reset_ctl(FrameCtl* ctl, uint32_t n_pri
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_scan: exclusive prefix of the per-block child bounds of generation `gen` (one block, no atomics),
-// plus the generation's hit total and the size of generation gen+1.  Child-ray ids become a pure
-// function of the ray order, so a frame always lays its rays out the same way.
+// k_scan: exclusive prefix of the per-block child bounds of generation `gen` (no atomics on the data), plus the
+// generation's hit total and the size of generation gen+1.  Child-ray ids become a pure function of the ray
+// order, so a frame always lays its rays out the same way.
+// Two levels in one launch: a block scans chunks of SCAN_CHUNK entries -- four consecutive entries per thread, one
+// 16-byte load each, so a wave reads 1 KiB in a row -- and leaves the prefixes inside each chunk in blk_base and the
+// chunk's totals in blk_top; the block that finishes last (one ticket per block, a few dozen in all) scans the chunk
+// totals.  A consumer adds blk_top's prefix of its chunk to blk_base (child_base()).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_scan(const uint32_t* blk_hits, const uint32_t* blk_children, uint32_t* blk_base, FrameCtl* ctl, int gen, long long capacity) {
-  __shared__ uint32_t s_c[16], s_h[16];
-  uint32_t start, count;
-  gen_range(ctl, gen, capacity, start, count);
-  const uint32_t n = (count + BLOCK - 1) / BLOCK;
-  const uint32_t per = (n + 1023u) / 1024u;
-  const uint32_t lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
-  uint32_t c = 0, h = 0;
-  for (uint32_t k = lo; k < hi; ++k) c += blk_children[k], h += blk_hits[k];
-  // inclusive scan inside each wave by shuffles, then the 16 wave totals through LDS: one barrier
+constexpr uint32_t SCAN_CHUNK = 4096;  // entries per block: 1024 threads x 4
+
+RT_FN uint32_t child_base(const uint32_t* blk_base, const uint32_t* blk_top, uint32_t k) { return blk_base[k] + blk_top[3u * (k / SCAN_CHUNK) + 2u]; }
+
+// inclusive scan over the 1024 threads of the block; *total = sum over the block.  s: 16 words of LDS.
+RT_FN uint32_t block_scan_1024(uint32_t v, uint32_t* s, uint32_t* total) {
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  uint32_t ic = c, ih = h;
+  uint32_t inc = v;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t tc = __shfl_up(ic, off), th = __shfl_up(ih, off);
-    if ((int)lane >= off) ic += tc, ih += th;
+    const uint32_t t = __shfl_up(inc, off);
+    if ((int)lane >= off) inc += t;
   }
-  if (lane == 63u) s_c[wave] = ic, s_h[wave] = ih;
+  if (lane == 63u) s[wave] = inc;
   __syncthreads();
-  uint32_t pc = 0, ph = 0;
-  for (uint32_t w = 0; w < wave; ++w) pc += s_c[w], ph += s_h[w];
-  uint32_t run = pc + ic - c;
-  for (uint32_t k = lo; k < hi; ++k) {
-    blk_base[k] = run;
-    run += blk_children[k];
+  uint32_t before = 0, all = 0;
+  for (uint32_t w = 0; w < 16u; ++w) {
+    const uint32_t x = s[w];
+    before += w < wave ? x : 0u;
+    all += x;
   }
-  if (threadIdx.x == 1023) {
-    ctl->hit_count[gen].v = ph + ih;
-    unsigned long long total = pc + ic;
+  __syncthreads();
+  *total = all;
+  return before + inc;
+}
+
+__global__ void __launch_bounds__(1024) k_scan(const uint32_t* blk_hits, const uint32_t* blk_children, uint32_t* blk_base, uint32_t* blk_top, FrameCtl* ctl, int gen, long long capacity) {
+  __shared__ uint32_t s_scan[16];
+  __shared__ uint32_t s_last;
+  uint32_t start, count;
+  gen_range(ctl, gen, capacity, start, count);
+  const uint32_t n = (count + GROUP - 1) / GROUP;
+  const uint32_t nchunk = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+  // the grid is fixed (the generation's size is known on the device only): a block takes the chunks
+  // blockIdx.x, blockIdx.x + gridDim.x, ... -- one each for all but the largest generations
+  for (uint32_t chunk = blockIdx.x; chunk < nchunk; chunk += gridDim.x) {  // block-uniform
+    const uint32_t k0 = chunk * SCAN_CHUNK + threadIdx.x * 4u;
+    uint32_t c[4] = {0, 0, 0, 0}, h[4] = {0, 0, 0, 0};
+    if (k0 + 3u < n) {  // the arrays are 16-byte aligned and k0 is a multiple of 4
+      const uint4 cv = *(const uint4*)(blk_children + k0), hv = *(const uint4*)(blk_hits + k0);
+      c[0] = cv.x, c[1] = cv.y, c[2] = cv.z, c[3] = cv.w, h[0] = hv.x, h[1] = hv.y, h[2] = hv.z, h[3] = hv.w;
+    } else {
+      for (uint32_t j = 0; j < 4u; ++j)
+        if (k0 + j < n) c[j] = blk_children[k0 + j], h[j] = blk_hits[k0 + j];
+    }
+    const uint32_t csum = c[0] + c[1] + c[2] + c[3], hsum = h[0] + h[1] + h[2] + h[3];
+    uint32_t ctot, htot;
+    const uint32_t cinc = block_scan_1024(csum, s_scan, &ctot);
+    (void)block_scan_1024(hsum, s_scan, &htot);
+    uint32_t run = cinc - csum;
+    if (k0 + 3u < n) {
+      *(uint4*)(blk_base + k0) = make_uint4(run, run + c[0], run + c[0] + c[1], run + c[0] + c[1] + c[2]);
+    } else {
+      for (uint32_t j = 0; j < 4u; ++j)
+        if (k0 + j < n) blk_base[k0 + j] = run, run += c[j];
+    }
+    if (threadIdx.x == 0) {  // chunk totals to memory every block can read
+      __hip_atomic_store(&blk_top[3u * chunk], ctot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&blk_top[3u * chunk + 1u], htot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // one ticket per block; the block that draws the last one scans the chunk totals
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const uint32_t ticket = __hip_atomic_fetch_add(&ctl->scan_ticket[gen].v, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = ticket == gridDim.x - 1u ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const uint32_t per = (nchunk + 1023u) / 1024u;
+  const uint32_t lo = threadIdx.x * per, hi = lo + per < nchunk ? lo + per : nchunk;
+  uint32_t mc = 0, mh = 0;
+  for (uint32_t k = lo; k < hi; ++k) {
+    mc += __hip_atomic_load(&blk_top[3u * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mh += __hip_atomic_load(&blk_top[3u * k + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  uint32_t all_c, all_h;
+  const uint32_t pc = block_scan_1024(mc, s_scan, &all_c);
+  (void)block_scan_1024(mh, s_scan, &all_h);
+  uint32_t prefix = pc - mc;
+  for (uint32_t k = lo; k < hi; ++k) {
+    blk_top[3u * k + 2u] = prefix;
+    prefix += __hip_atomic_load(&blk_top[3u * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x == 0) {
+    ctl->hit_count[gen].v = all_h;
+    unsigned long long total = all_c;
     const unsigned long long room = (unsigned long long)capacity - ((unsigned long long)start + count);
     if (total > room) total = room, ctl->overflow.v = 1;
     ctl->gen_count[gen + 1].v = (uint32_t)total;
@@ -1283,11 +1460,11 @@ RT_FN void container_indices(const DevScene<R>& sc, bool need, int p, PrimInfo i
 // One thread per ray; lanes whose ray missed idle.
 // ------------------------------------------------------------------------------------------------
 template <class R, bool COUNT, bool PACKET>
-__global__ void __launch_bounds__(256, PACKET ? RT355_WPS_PACKET : RT355_WPS_LANE) k_shadow(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int launch) {
+__global__ void __launch_bounds__(BLOCK, PACKET ? RT355_WPS_PACKET : RT355_WPS_LANE) k_shadow(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int launch) {
   uint32_t start, gcount;
   gen_range(ctl, gen, pool.capacity, start, gcount);
-  __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
-  int* lds = PACKET ? lds_stack + (threadIdx.x >> 6) * STACK_DEPTH : lds_stack + threadIdx.x;
+  __shared__ int lds_stack[PACKET ? 1 : LDS_STACK * BLOCK];  // the packet traversal keeps its stack in a register
+  int* lds = lds_stack + (PACKET ? 0 : threadIdx.x);
   Work wk;
   for (uint32_t rbase = blockIdx.x * BLOCK; rbase < gcount; rbase += gridDim.x * BLOCK) {
     const uint32_t i = rbase + threadIdx.x;
@@ -1306,7 +1483,7 @@ __global__ void __launch_bounds__(256, PACKET ? RT355_WPS_PACKET : RT355_WPS_LAN
 // Everything a wave exchanges through LDS is its own (no block barrier); LDS operations of one wave execute
 // in order, the fences only keep the compiler from moving them.
 template <class R, bool COUNT>
-__global__ void __launch_bounds__(256, 4) k_shadow_q(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int launch) {
+__global__ void __launch_bounds__(BLOCK, 4) k_shadow_q(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int launch) {
   uint32_t start, gcount;
   gen_range(ctl, gen, pool.capacity, start, gcount);
   __shared__ int lds_stack[QUADS * STACK_DEPTH];
@@ -1369,19 +1546,17 @@ __global__ void __launch_bounds__(256, 4) k_shadow_q(DevScene<R> sc, RayPool<R> 
 // shapes.  Launched while rays may still be spawned (remaining > 0); the deepest generation has no
 // children and k_combine is told so.
 // ------------------------------------------------------------------------------------------------
-// One chunk of BLOCK rays: the child rays of its hits are placed from `base` (an offset into generation
-// gen + 1) on, reflected before refracted inside each wave, waves in order.  Called by every thread of the
-// block (it synchronises the block).
+// The 64 rays of one wave: the child rays of their hits are placed from `base` (an offset into generation gen + 1,
+// this wave's own prefix) on, reflected before refracted.  Called by every lane of the wave.
 template <class R, bool COUNT, bool PACKET>
-RT_FN void spawn_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* ctl, int gen, uint32_t start, uint32_t gcount, uint32_t rbase, uint32_t base,
-                       int any_transparent, int* lds, uint32_t* s_cnt, Work& wk) {
+RT_FN void spawn_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* ctl, int gen, uint32_t start, uint32_t gcount, uint32_t i,
+                       int any_transparent, int* lds, Work& wk) {
   const uint32_t child_start = start + gcount;
-  const uint32_t wave = threadIdx.x >> 6;
-  const uint32_t i = rbase + threadIdx.x;
   const uint32_t r = start + (i < gcount ? i : 0u);
   const int p_raw = pool.hit_prim[r];
   const bool valid = i < gcount && p_raw >= 0;
-  if (__syncthreads_or(valid) == 0) return;  // block-uniform
+  if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;  // wave-uniform
+  const uint32_t base = child_base(pool.blk_base, pool.blk_top, __builtin_amdgcn_readfirstlane(i) / GROUP);
   const int p = valid ? p_raw : 0;
   const PrimInfo info = sc.prim_info[p];
   const bool slot_r = valid && (info.flags & PF_REFLECTIVE);
@@ -1429,17 +1604,12 @@ RT_FN void spawn_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* 
     }
   }
 
-  // child ids: the chunk's base + rank inside the chunk; the bound counts a refracted ray for every
+  // child ids: the wave's base + rank inside the wave; the bound counts a refracted ray for every
   // transparent hit, so a hit that turns out to be total internal reflection leaves its slot empty (zero
   // direction = no ray).
   const unsigned long long m_r = __ballot(slot_r), m_t = __ballot(slot_t);
   const uint32_t n_r = __popcll(m_r);
-  if ((threadIdx.x & 63u) == 0) s_cnt[wave] = n_r + __popcll(m_t);
-  __syncthreads();
-  for (int w = 0; w < BLOCK / 64; ++w)
-    if (w < (int)wave) base += s_cnt[w];
   const uint32_t off_r = __popcll(m_r & lanes_below()), off_t = n_r + __popcll(m_t & lanes_below());
-  __syncthreads();
   const uint32_t n_holes = __popcll(__ballot(slot_t && !want_refr));
   if ((threadIdx.x & 63u) == 0 && n_holes) atomicAdd(&ctl->holes[gen + 1].v, n_holes);
 
@@ -1472,75 +1642,14 @@ RT_FN void spawn_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* 
 }
 
 template <class R, bool COUNT, bool PACKET>
-__global__ void __launch_bounds__(256, PACKET ? RT355_WPS_SPAWN_PACKET : RT355_WPS_SPAWN) k_spawn(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int any_transparent, int launch) {
-  __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
-  int* lds = PACKET ? lds_stack + (threadIdx.x >> 6) * STACK_DEPTH : lds_stack + threadIdx.x;
+__global__ void __launch_bounds__(BLOCK, PACKET ? RT355_WPS_SPAWN_PACKET : RT355_WPS_SPAWN) k_spawn(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int any_transparent, int launch) {
+  __shared__ int lds_stack[PACKET ? 1 : LDS_STACK * BLOCK];
+  int* lds = lds_stack + (PACKET ? 0 : threadIdx.x);
   Work wk;
   uint32_t start, gcount;
   gen_range(ctl, gen, pool.capacity, start, gcount);
-  __shared__ uint32_t s_cnt[BLOCK / 64];
-  // block-uniform trip count: every wave reaches the barriers
   for (uint32_t rbase = blockIdx.x * BLOCK; rbase < gcount; rbase += gridDim.x * BLOCK)
-    spawn_chunk<R, COUNT, PACKET>(sc, pool, ctl, gen, start, gcount, rbase, pool.blk_base[rbase / BLOCK], any_transparent, lds, s_cnt, wk);
-  flush_work<COUNT>(ctl, launch, wk);
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_trace_spawn: k_trace, k_scan and k_spawn of one generation in ONE launch.  A block traces its chunks,
-// takes the slots of all their child rays with a single atomic on the next generation's size (one word takes
-// fewer than 100 atomics per microsecond, so a block of a large generation takes several chunks per atomic),
-// then writes the children.  The order in which blocks get their slots varies from run to run; nothing
-// depends on it, a ray's colour is a function of the ray alone.  Saves two dependent launches per generation.
-// ------------------------------------------------------------------------------------------------
-constexpr int MAX_CPB = 4;  // chunks a block takes per trip at most
-
-template <class R, bool COUNT, bool PACKET>
-__global__ void __launch_bounds__(256, 3) k_trace_spawn(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch, DevCamera<R> cam, int primary, int any_transparent) {
-  __shared__ int lds_stack[PACKET ? (BLOCK / 64) * STACK_DEPTH : LDS_STACK * BLOCK];
-  int* lds = PACKET ? lds_stack + (threadIdx.x >> 6) * STACK_DEPTH : lds_stack + threadIdx.x;
-  __shared__ uint32_t s_red[2 * (BLOCK / 64)], s_cnt[BLOCK / 64], s_chunk[MAX_CPB], s_base;
-  uint32_t start, count;
-  gen_range(ctl, gen, pool.capacity, start, count);
-  const uint32_t nchunks = (count + BLOCK - 1) / BLOCK;
-  uint32_t cpb = (nchunks + gridDim.x - 1) / gridDim.x;
-  cpb = cpb < 1u ? 1u : (cpb > (uint32_t)MAX_CPB ? (uint32_t)MAX_CPB : cpb);
-  const uint32_t trips = (nchunks + cpb - 1) / cpb;
-  Work wk;
-  // A trip takes the chunks trip, trip + trips, ...: neighbouring chunks cost alike (they are neighbouring
-  // image regions), so the expensive ones spread over the blocks.  Trip and chunk counts are block-uniform.
-  for (uint32_t trip = blockIdx.x; trip < trips; trip += gridDim.x) {
-    uint32_t hits = 0;  // thread 0 only
-    for (uint32_t c = 0; c < cpb; ++c) {
-      const uint32_t chunk = trip + c * trips;
-      if (threadIdx.x == 0) s_chunk[c] = 0;
-      if (chunk >= nchunks) continue;
-      uint32_t wh, wc;
-      trace_chunk<R, COUNT, PACKET, false>(sc, pool, ctl, cam, primary, start, count, chunk * BLOCK, remaining, launch, lds, wk, wh, wc);
-      if ((threadIdx.x & 63u) == 0) s_red[threadIdx.x >> 6] = wh, s_red[BLOCK / 64 + (threadIdx.x >> 6)] = wc;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        uint32_t tc = 0;
-        for (int w = 0; w < BLOCK / 64; ++w) hits += s_red[w], tc += s_red[BLOCK / 64 + w];
-        s_chunk[c] = tc;
-      }
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-      uint32_t total = 0;
-      for (uint32_t c = 0; c < cpb; ++c) total += s_chunk[c];
-      s_base = total ? atomicAdd(&ctl->gen_count[gen + 1].v, total) : 0u;
-      if (hits) atomicAdd(&ctl->hit_count[gen].v, hits);
-    }
-    __syncthreads();
-    uint32_t base = s_base;
-    for (uint32_t c = 0; c < cpb; ++c) {
-      const uint32_t n = s_chunk[c];  // block-uniform
-      if (n == 0) continue;
-      spawn_chunk<R, COUNT, PACKET>(sc, pool, ctl, gen, start, count, (trip + c * trips) * BLOCK, base, any_transparent, lds, s_cnt, wk);
-      base += n;
-    }
-    __syncthreads();
-  }
+    spawn_chunk<R, COUNT, PACKET>(sc, pool, ctl, gen, start, gcount, rbase + threadIdx.x, any_transparent, lds, wk);
   flush_work<COUNT>(ctl, launch, wk);
 }
 
@@ -1603,7 +1712,7 @@ template <class R, int LEVELS>
 __global__ void __launch_bounds__(256) k_combine(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int has_children, DevCamera<R> cam, int mode, float* out) {
   uint32_t start, gcount;
   gen_range(ctl, gen, pool.capacity, start, gcount);
-  for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < gcount; i += gridDim.x * BLOCK) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < gcount; i += gridDim.x * blockDim.x) {
     const uint32_t r = start + i;
     const V3<R> c = ray_colour<R, LEVELS>(sc, pool, r, has_children != 0);
     if (gen > 0 || mode == OUT_NONE) st3(pool.color + 3ull * r, c);
@@ -1631,7 +1740,7 @@ __global__ void __launch_bounds__(256) k_untile(const T* gathered, T* out, int w
 
 // World::is_shadowed for arbitrary points (parity probe)
 template <class R>
-__global__ void __launch_bounds__(256) k_shadow_points(DevScene<R> sc, const float* pts, uint32_t n, uint8_t* out) {
+__global__ void __launch_bounds__(BLOCK) k_shadow_points(DevScene<R> sc, const float* pts, uint32_t n, uint8_t* out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   __shared__ int lds_stack[LDS_STACK * BLOCK];
@@ -1647,7 +1756,7 @@ __global__ void __launch_bounds__(256) k_shadow_points(DevScene<R> sc, const flo
 
 // the same with the quad traversal: four lanes to a point
 template <class R>
-__global__ void __launch_bounds__(256) k_shadow_points_q(DevScene<R> sc, const float* pts, uint32_t n, uint8_t* out) {
+__global__ void __launch_bounds__(BLOCK) k_shadow_points_q(DevScene<R> sc, const float* pts, uint32_t n, uint8_t* out) {
   __shared__ int lds_stack[QUADS * STACK_DEPTH];
   const uint32_t i = blockIdx.x * QUADS + (threadIdx.x >> 2);
   if (i >= n) return;  // whole quads leave together

@@ -93,8 +93,7 @@ constexpr int64_t PACKET_SECONDARY_PRIMS = 64;  // scenes with at most this many
 struct LaunchLog {
   int n = 0;
   int depth = 0;  // deepest generation
-  bool fused = false;      // k_trace_spawn launches: a trace launch also allocates and writes the child rays
-  bool fused_last = true;  // its trace launch also shades (k_trace<..., LAST>); false: a shadow launch of its own
+  bool shaded_in_trace = true;  // its trace launch also shades (k_trace<..., LAST>); false: a shadow launch of its own
   int kind[RT355_MAX_LAUNCH], gen[RT355_MAX_LAUNCH];
 };
 
@@ -117,11 +116,9 @@ struct rt355_ctx {
   int shadow_lag = 0;   // the shadow launch of generation g is released behind the spawn of generation g + lag
   int use_side = 1;     // shadow launches on the side stream (0: everything on the main stream, e.g. with several frames in flight)
   int quad = 0;         // generations beyond packet_gens, four lanes to a ray instead of one: bit 0 k_trace_q, bit 1 k_shadow_q
-  int fused = 0;        // k_trace_spawn: trace + slot allocation + spawn of a generation in one launch (0: k_trace, k_scan, k_spawn)
   uint32_t grid0_cap = 0;  // blocks of a generation-0 launch at most (set to 32 per CU at creation; 0: one block per 256 rays).  A capped grid
                            // walks its rays in several trips, which spreads each wave's start-up (some 150 instructions) over more rays
-  uint32_t fused_grid = 4096;  // blocks of a k_trace_spawn launch at most; larger generations take several chunks per block
-  DevBuf org, dir, hit_t, hit_uv, hit_prim, color, mixr, child, blk_hits, blk_children, blk_base, ctl, io_in, io_out, io_out2;
+  DevBuf org, dir, hit_t, hit_uv, hit_prim, color, mixr, child, blk_hits, blk_children, blk_base, blk_top, ctl, io_in, io_out, io_out2;
   hipEvent_t ev[RT355_MAX_LAUNCH + 1] = {};  // timing mode: one before every launch, one behind the last
   FrameCtl* ctl_host = nullptr;  // pinned
   void* views_dev = nullptr;   // the views of a batch of frames (RT355_MAX_BATCH x DevView<double>), read by generation 0
@@ -242,6 +239,9 @@ int64_t tiles_per_rank_of(int width, int height, int n_ranks) {
   return (tx * ty + n_ranks - 1) / n_ranks;
 }
 
+// blocks of a k_scan launch over a generation of at most `rays` rays
+uint32_t scan_blocks(uint64_t rays) { return std::max<uint32_t>(1u, (uint32_t)(((rays + GROUP - 1) / GROUP + SCAN_CHUNK - 1) / SCAN_CHUNK)); }
+
 template <class R>
 int ensure_pool(rt355_ctx* c, uint64_t n_primary, bool secondary, RayPool<R>& pool) {
   double factor = secondary ? std::max(1.0, c->pool_factor) : 1.0;
@@ -256,15 +256,17 @@ int ensure_pool(rt355_ctx* c, uint64_t n_primary, bool secondary, RayPool<R>& po
   if ((rc = c->color.ensure(cap * 3 * sizeof(R)))) return rc;
   if ((rc = c->mixr.ensure(cap * sizeof(R)))) return rc;
   if ((rc = c->child.ensure(cap * 2 * sizeof(int32_t)))) return rc;
-  const uint64_t nblk = cap / BLOCK + 2;
+  const uint64_t nblk = cap / GROUP + 8;
   if ((rc = c->blk_hits.ensure(nblk * sizeof(uint32_t)))) return rc;
   if ((rc = c->blk_children.ensure(nblk * sizeof(uint32_t)))) return rc;
   if ((rc = c->blk_base.ensure(nblk * sizeof(uint32_t)))) return rc;
+  if ((rc = c->blk_top.ensure((scan_blocks(cap) + 1) * 3 * sizeof(uint32_t)))) return rc;
   if ((rc = c->ctl.ensure(sizeof(FrameCtl)))) return rc;
   pool.org = (R*)c->org.p, pool.dir = (R*)c->dir.p, pool.hit_t = (R*)c->hit_t.p, pool.hit_uv = (R*)c->hit_uv.p;
   pool.hit_prim = (int32_t*)c->hit_prim.p, pool.color = (R*)c->color.p, pool.mixr = (R*)c->mixr.p;
   pool.child = (int32_t*)c->child.p;
   pool.blk_hits = (uint32_t*)c->blk_hits.p, pool.blk_children = (uint32_t*)c->blk_children.p, pool.blk_base = (uint32_t*)c->blk_base.p;
+  pool.blk_top = (uint32_t*)c->blk_top.p;
   pool.capacity = (int64_t)cap;
   return RT355_OK;
 }
@@ -275,7 +277,7 @@ template <class R>
 int carve_pool(rt355_ctx* c, void* base, size_t bytes, uint64_t n_primary, bool secondary, RayPool<R>& pool, FrameCtl** ctl) {
   const double factor = secondary ? std::max(1.0, c->pool_factor) : 1.0;
   const uint64_t cap = (uint64_t)std::ceil((double)n_primary * factor) + 64;
-  const uint64_t nblk = cap / BLOCK + 2;
+  const uint64_t nblk = cap / GROUP + 8;
   size_t off = 0;
   auto take = [&](size_t n) {
     void* p = (unsigned char*)base + off;
@@ -289,6 +291,7 @@ int carve_pool(rt355_ctx* c, void* base, size_t bytes, uint64_t n_primary, bool 
   pool.mixr = (R*)take(cap * sizeof(R)), pool.child = (int32_t*)take(cap * 2 * sizeof(int32_t));
   pool.blk_hits = (uint32_t*)take(nblk * sizeof(uint32_t)), pool.blk_children = (uint32_t*)take(nblk * sizeof(uint32_t));
   pool.blk_base = (uint32_t*)take(nblk * sizeof(uint32_t));
+  pool.blk_top = (uint32_t*)take((scan_blocks(cap) + 1) * 3 * sizeof(uint32_t));
   pool.capacity = (int64_t)cap;
   if (off > bytes)
     return set_err(RT355_ECAPACITY, "frame too large for the fixed workspace: " + std::to_string(off) + " bytes needed, " + std::to_string(bytes) +
@@ -313,7 +316,7 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, FrameC
   const int block = BLOCK;
   uint32_t grid0 = (n_primary + BLOCK - 1) / BLOCK;  // one block per 256 rays
   if (c->grid0_cap) grid0 = std::min(grid0, c->grid0_cap);
-  const uint32_t grid_cap = (uint32_t)c->n_cu * 16;
+  const uint32_t grid_cap = (uint32_t)c->n_cu * 16 * (256 / BLOCK);
   auto rec = [&](int kind, int gen) {
     if (c->timing && log.n < RT355_MAX_LAUNCH) HIP_TRY(hipEventRecord(c->ev[log.n], c->stream));
     if (log.n < RT355_MAX_LAUNCH) log.kind[log.n] = kind, log.gen[log.n] = gen;
@@ -330,47 +333,34 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, FrameC
     const bool packet = g < packet_gens;
     const bool quad = !packet && (c->quad & 1);
     const bool last = g == depth;
-    const bool fused = c->fused && !quad;  // trace, slot allocation and spawn of the generation in one launch
     const int prim = (g == 0 && primary) ? 1 : 0, any_t = s->any_transparent ? 1 : 0;
     // with the side stream in use, the event it waits for rides on the completion signal of the generation's
     // last launch on the main stream: a separate event record would put a marker packet, and some
     // microseconds, between that launch and the next trace
     hipEvent_t done = (overlap && !last) ? c->ev_traced[g] : nullptr;
-    if (fused && !last) {
-      // grid: one block per chunk up to the cap; beyond it a block takes several chunks per slot allocation
-      const uint32_t fgrid = std::min<uint32_t>(grid, c->fused_grid);
+    if (quad)  // the deepest generation is shaded by a k_shadow_q launch of its own, below
+      hipLaunchKernelGGL((k_trace_q<R, COUNT>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n, cam, prim);
+    else if (packet && last)
+      hipLaunchKernelGGL((k_trace<R, COUNT, true, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, 0, log.n, cam, prim);
+    else if (packet)
+      hipLaunchKernelGGL((k_trace<R, COUNT, true, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n, cam, prim);
+    else if (last)
+      hipLaunchKernelGGL((k_trace<R, COUNT, false, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, 0, log.n, cam, prim);
+    else
+      hipLaunchKernelGGL((k_trace<R, COUNT, false, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n, cam, prim);
+    log.n++;
+    if ((rc = rec(RT355_K_SCAN, g))) return rc;
+    hipLaunchKernelGGL(k_scan, dim3(std::min<uint32_t>(64u, scan_blocks(std::min<uint64_t>((uint64_t)pool.capacity, (uint64_t)n_primary << g)))), dim3(1024), 0, c->stream, pool.blk_hits, pool.blk_children, pool.blk_base,
+                       pool.blk_top, ctl, g, (long long)pool.capacity);
+    log.n++;
+    if (g < depth) {  // the deepest generation spawns nothing
+      if ((rc = rec(RT355_K_SPAWN, g))) return rc;
+      const int launch_id = log.n;
       if (packet)
-        hipExtLaunchKernelGGL((k_trace_spawn<R, COUNT, true>), dim3(fgrid), dim3(block), 0, c->stream, nullptr, done, 0, sc, pool, ctl, g, depth - g, log.n, cam, prim, any_t);
+        hipExtLaunchKernelGGL((k_spawn<R, COUNT, true>), dim3(grid), dim3(block), 0, c->stream, nullptr, done, 0, sc, pool, ctl, g, any_t, launch_id);
       else
-        hipExtLaunchKernelGGL((k_trace_spawn<R, COUNT, false>), dim3(fgrid), dim3(block), 0, c->stream, nullptr, done, 0, sc, pool, ctl, g, depth - g, log.n, cam, prim, any_t);
+        hipExtLaunchKernelGGL((k_spawn<R, COUNT, false>), dim3(grid), dim3(block), 0, c->stream, nullptr, done, 0, sc, pool, ctl, g, any_t, launch_id);
       log.n++;
-    } else {
-      const int count_hits = fused ? 1 : 0;  // fused frame, deepest generation: no k_scan follows
-      if (quad)  // the deepest generation is shaded by a k_shadow_q launch of its own, below
-        hipLaunchKernelGGL((k_trace_q<R, COUNT>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n, cam, prim);
-      else if (packet && last)
-        hipLaunchKernelGGL((k_trace<R, COUNT, true, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, 0, log.n, cam, prim, count_hits);
-      else if (packet)
-        hipLaunchKernelGGL((k_trace<R, COUNT, true, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n, cam, prim, count_hits);
-      else if (last)
-        hipLaunchKernelGGL((k_trace<R, COUNT, false, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, 0, log.n, cam, prim, count_hits);
-      else
-        hipLaunchKernelGGL((k_trace<R, COUNT, false, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n, cam, prim, count_hits);
-      log.n++;
-      if (!fused) {
-        if ((rc = rec(RT355_K_SCAN, g))) return rc;
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, pool.blk_hits, pool.blk_children, pool.blk_base, ctl, g, (long long)pool.capacity);
-        log.n++;
-        if (g < depth) {  // the deepest generation spawns nothing
-          if ((rc = rec(RT355_K_SPAWN, g))) return rc;
-          const int launch_id = log.n;
-          if (packet)
-            hipExtLaunchKernelGGL((k_spawn<R, COUNT, true>), dim3(grid), dim3(block), 0, c->stream, nullptr, done, 0, sc, pool, ctl, g, any_t, launch_id);
-          else
-            hipExtLaunchKernelGGL((k_spawn<R, COUNT, false>), dim3(grid), dim3(block), 0, c->stream, nullptr, done, 0, sc, pool, ctl, g, any_t, launch_id);
-          log.n++;
-        }
-      }
     }
     // Shadow launches.  The one of generation g - lag is released here, behind the spawn of generation g:
     // the next trace then reaches the device first and the shadow waves fill the SIMDs its tail leaves
@@ -405,8 +395,7 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, FrameC
     }
   }
   log.depth = depth;
-  log.fused_last = !(depth >= packet_gens && (c->quad & 1));
-  log.fused = c->fused && !(c->quad & 1);
+  log.shaded_in_trace = !(depth >= packet_gens && (c->quad & 1));
   if (overlap && depth > 0) {
     HIP_TRY(hipEventRecord(c->ev_side_done, c->side));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_side_done, 0));
@@ -418,15 +407,16 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, FrameC
   const int levels = std::max(0, std::min(c->combine_levels, depth - 1));
   const int top = depth > 0 ? depth - 1 - levels : 0;
   for (int g = top; g >= 0; --g) {
-    const uint32_t grid = g == 0 ? grid0 : std::min<uint32_t>(grid_cap, (uint32_t)((pool.capacity + BLOCK - 1) / BLOCK));
+    // no traversal here: 256-thread blocks
+    const uint32_t grid = std::max<uint32_t>(1u, (g == 0 ? grid0 : std::min<uint32_t>(grid_cap, (uint32_t)((pool.capacity + BLOCK - 1) / BLOCK))) / (256 / BLOCK));
     int rc;
     if ((rc = rec(RT355_K_COMBINE, g))) return rc;
     const int has_children = g < depth ? 1 : 0;
     switch (g == top ? levels : 0) {
-      case 3: hipLaunchKernelGGL((k_combine<R, 3>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, has_children, cam, out_mode, out_dev); break;
-      case 2: hipLaunchKernelGGL((k_combine<R, 2>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, has_children, cam, out_mode, out_dev); break;
-      case 1: hipLaunchKernelGGL((k_combine<R, 1>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, has_children, cam, out_mode, out_dev); break;
-      default: hipLaunchKernelGGL((k_combine<R, 0>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, has_children, cam, out_mode, out_dev); break;
+      case 3: hipLaunchKernelGGL((k_combine<R, 3>), dim3(grid), dim3(256), 0, c->stream, sc, pool, ctl, g, has_children, cam, out_mode, out_dev); break;
+      case 2: hipLaunchKernelGGL((k_combine<R, 2>), dim3(grid), dim3(256), 0, c->stream, sc, pool, ctl, g, has_children, cam, out_mode, out_dev); break;
+      case 1: hipLaunchKernelGGL((k_combine<R, 1>), dim3(grid), dim3(256), 0, c->stream, sc, pool, ctl, g, has_children, cam, out_mode, out_dev); break;
+      default: hipLaunchKernelGGL((k_combine<R, 0>), dim3(grid), dim3(256), 0, c->stream, sc, pool, ctl, g, has_children, cam, out_mode, out_dev); break;
     }
     log.n++;
   }
@@ -472,9 +462,9 @@ int finish_stats(rt355_ctx* c, const LaunchLog& log, double frame_ms, rt355_stat
       st->launch_max_box_tests[i] = w[10];
       st->launch_max_wave_clocks[i] = w[11];
       const int g = log.gen[i];
-      if (log.kind[i] == RT355_K_SHADE || (log.kind[i] == RT355_K_TRACE && g == log.depth && log.fused_last))
+      if (log.kind[i] == RT355_K_SHADE || (log.kind[i] == RT355_K_TRACE && g == log.depth && log.shaded_in_trace))
         fl += F_SHADE * (double)hits_of[g];  // over_point + lighting of every hit
-      if (log.kind[i] == RT355_K_SPAWN || (log.kind[i] == RT355_K_TRACE && log.fused && g < log.depth))
+      if (log.kind[i] == RT355_K_SPAWN)
         fl += 0.5 * (F_REFLECT + F_REFRACT) * (double)h.gen_count[g + 1].v;
       if (log.kind[i] == RT355_K_COMBINE) fl += 8.0 * (double)hits_of[g];  // surface + refl * R + refr * (1 - R)
       st->launch_flops[i] = fl;
@@ -545,7 +535,7 @@ int rays_impl(rt355_ctx* c, const rt355_scene* s, const float* rays_host, size_t
   if ((rc = ensure_pool<R>(c, n, !trace_only && s->any_secondary && max_depth > 0, pool))) return rc;
   if ((rc = c->io_in.ensure(n * 6 * sizeof(float)))) return rc;
   HIP_TRY(hipMemcpyAsync(c->io_in.p, rays_host, n * 6 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  const int block = 256;
+  const int block = BLOCK;
   const uint32_t grid0 = (uint32_t)((n + block - 1) / block);
   hipLaunchKernelGGL((k_load_rays<R>), dim3(grid0), dim3(block), 0, c->stream, (const float*)c->io_in.p, pool, (uint32_t)n);
   LaunchLog log;
@@ -556,7 +546,7 @@ int rays_impl(rt355_ctx* c, const rt355_scene* s, const float* rays_host, size_t
     if (c->quad & 1)
       hipLaunchKernelGGL((k_trace_q<R, false>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (FrameCtl*)c->ctl.p, 0, 0, 0, DevCamera<R>{}, 0);
     else
-      hipLaunchKernelGGL((k_trace<R, false, false, false>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (FrameCtl*)c->ctl.p, 0, 0, 0, DevCamera<R>{}, 0, 0);
+      hipLaunchKernelGGL((k_trace<R, false, false, false>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (FrameCtl*)c->ctl.p, 0, 0, 0, DevCamera<R>{}, 0);
     if ((rc = c->io_out.ensure(n * sizeof(double)))) return rc;
     if ((rc = c->io_out2.ensure(n * sizeof(int32_t)))) return rc;
     hipLaunchKernelGGL((k_export_hits<R>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (uint32_t)n, (double*)c->io_out.p, (int32_t*)c->io_out2.p);
@@ -596,12 +586,16 @@ int upload_impl(rt355_ctx* c, const HostScene& hs, rt355_scene* s) {
     auto up = [](double v) { float r = (float)v; if ((double)r < v) r = std::nextafter(r, std::numeric_limits<float>::infinity()); return r; };
     for (int k = 0; k < BVH_WIDTH; ++k) {
       for (int a = 0; a < 3; ++a) {
-        nodes[i].box[k][a] = down(hs.nodes[i].lo[k][a]), nodes[i].box[k][3 + a] = up(hs.nodes[i].hi[k][a]);
+        nodes[i].box[k][2 * a] = down(hs.nodes[i].lo[k][a]), nodes[i].box[k][2 * a + 1] = up(hs.nodes[i].hi[k][a]);
         if (i == 0)  // node 0 is the root: its boxes enclose every other
-          for (float v : {nodes[i].box[k][a], nodes[i].box[k][3 + a]})
+          for (float v : {nodes[i].box[k][2 * a], nodes[i].box[k][2 * a + 1]})
             if (std::isfinite(v)) s->box_abs_max = std::max(s->box_abs_max, std::fabs(v));
       }
       nodes[i].c[k] = hs.nodes[i].c[k];
+      if (nodes[i].c[k] == -1) {  // empty slot: both x planes at +inf, which no ray interval with finite ends overlaps
+        nodes[i].box[k][0] = nodes[i].box[k][1] = std::numeric_limits<float>::infinity();
+        for (int a = 2; a < 6; ++a) nodes[i].box[k][a] = 0.f;
+      }
     }
     for (int k = 0; k < 4; ++k) nodes[i].pad[k] = 0;
   }
@@ -710,7 +704,7 @@ int rt355_ctx_create_ex(rt355_ctx** out, int device_id, int real_bits, int flags
   c->device = device_id, c->real_bits = real_bits;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
-  c->grid0_cap = (uint32_t)c->n_cu * 32;
+  c->grid0_cap = (uint32_t)c->n_cu * 32 * (256 / BLOCK);
   // Main stream: the chain every generation waits on, at the highest priority the device offers.  Side
   // stream: the shadow launches, at the lowest, so that their waves yield to the chain's (measured: 2 % of
   // the frame).
@@ -749,9 +743,7 @@ int rt355_ctx_create_ex(rt355_ctx** out, int device_id, int real_bits, int flags
   if (const char* e = getenv("RT355_COMBINE_LEVELS")) c->combine_levels = std::max(0, std::min(3, atoi(e)));
   if (const char* e = getenv("RT355_SHADOW_LAG")) c->shadow_lag = std::max(0, atoi(e));
   if (const char* e = getenv("RT355_QUAD")) c->quad = atoi(e) & 3;
-  if (const char* e = getenv("RT355_FUSED")) c->fused = atoi(e) != 0;
   if (const char* e = getenv("RT355_GRID0_CAP")) c->grid0_cap = (uint32_t)std::max(0, atoi(e));
-  if (const char* e = getenv("RT355_FUSED_GRID")) c->fused_grid = (uint32_t)std::max(64, std::min(1 << 20, atoi(e)));
   *out = c;
   return RT355_OK;
 }
@@ -761,7 +753,7 @@ void rt355_ctx_destroy(rt355_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->side) (void)hipStreamSynchronize(c->side);
-  for (DevBuf* b : {&c->org, &c->dir, &c->hit_t, &c->hit_uv, &c->hit_prim, &c->color, &c->mixr, &c->child, &c->blk_hits, &c->blk_children, &c->blk_base, &c->ctl, &c->io_in, &c->io_out, &c->io_out2}) b->release();
+  for (DevBuf* b : {&c->org, &c->dir, &c->hit_t, &c->hit_uv, &c->hit_prim, &c->color, &c->mixr, &c->child, &c->blk_hits, &c->blk_children, &c->blk_base, &c->blk_top, &c->ctl, &c->io_in, &c->io_out, &c->io_out2}) b->release();
   for (hipEvent_t e : c->ev)
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_traced)
@@ -1024,16 +1016,16 @@ int rt355_is_shadowed(rt355_ctx* c, const rt355_scene* s, const float* points, s
   if ((rc = c->io_out.ensure(n))) return rc;
   HIP_TRY(hipMemcpyAsync(c->io_in.p, points, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
   if (n >= 0x3fffffffull) return set_err(RT355_EINVAL, "too many points in one call");
-  const unsigned grid = (unsigned)((n + 255) / 256), grid_q = (unsigned)((n + QUADS - 1) / QUADS);
+  const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK), grid_q = (unsigned)((n + QUADS - 1) / QUADS);
   if (c->quad & 2) {  // the traversal the frame's shadow launches use
     if (c->real_bits == 32)
-      hipLaunchKernelGGL((k_shadow_points_q<float>), dim3(grid_q), dim3(256), 0, c->stream, dev_scene<float>(s), (const float*)c->io_in.p, (uint32_t)n, (uint8_t*)c->io_out.p);
+      hipLaunchKernelGGL((k_shadow_points_q<float>), dim3(grid_q), dim3(BLOCK), 0, c->stream, dev_scene<float>(s), (const float*)c->io_in.p, (uint32_t)n, (uint8_t*)c->io_out.p);
     else
-      hipLaunchKernelGGL((k_shadow_points_q<double>), dim3(grid_q), dim3(256), 0, c->stream, dev_scene<double>(s), (const float*)c->io_in.p, (uint32_t)n, (uint8_t*)c->io_out.p);
+      hipLaunchKernelGGL((k_shadow_points_q<double>), dim3(grid_q), dim3(BLOCK), 0, c->stream, dev_scene<double>(s), (const float*)c->io_in.p, (uint32_t)n, (uint8_t*)c->io_out.p);
   } else if (c->real_bits == 32)
-    hipLaunchKernelGGL((k_shadow_points<float>), dim3(grid), dim3(256), 0, c->stream, dev_scene<float>(s), (const float*)c->io_in.p, (uint32_t)n, (uint8_t*)c->io_out.p);
+    hipLaunchKernelGGL((k_shadow_points<float>), dim3(grid), dim3(BLOCK), 0, c->stream, dev_scene<float>(s), (const float*)c->io_in.p, (uint32_t)n, (uint8_t*)c->io_out.p);
   else
-    hipLaunchKernelGGL((k_shadow_points<double>), dim3(grid), dim3(256), 0, c->stream, dev_scene<double>(s), (const float*)c->io_in.p, (uint32_t)n, (uint8_t*)c->io_out.p);
+    hipLaunchKernelGGL((k_shadow_points<double>), dim3(grid), dim3(BLOCK), 0, c->stream, dev_scene<double>(s), (const float*)c->io_in.p, (uint32_t)n, (uint8_t*)c->io_out.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, c->io_out.p, n, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));

@@ -19,7 +19,9 @@ constexpr int TILE = 32;             // image tile edge; tile t belongs to rank 
 constexpr int TILE_PIX = TILE * TILE;
 constexpr int STACK_DEPTH = 64;      // traversal stack entries; the builder rejects trees that could need more
 constexpr int LDS_STACK = 24;        // of which this many live in LDS (one column per lane); the rest in scratch
-constexpr int BLOCK = 256;           // threads per block of the traversal kernels
+constexpr int BLOCK = 64;            // threads per block of the traversal kernels: one wave.  No kernel synchronises across waves, and a
+                                     // block's wave slots return to the dispatcher only when its last wave ends
+constexpr int GROUP = 64;            // rays per entry of the child-slot bookkeeping: the rays of one wave
 // Waves per SIMD the per-lane kernels are compiled for (the register budget is 512 / this per lane).
 #ifndef RT355_WPS_LANE
 #define RT355_WPS_LANE 3
@@ -60,10 +62,10 @@ struct PrimInfo {
 };
 
 // One node of the 4-wide BVH, 128 bytes.  Boxes are stored in float, rounded outward, whatever the
-// arithmetic type of the intersection tests is.  Unused child slots hold an inverted box (lo = +inf,
-// hi = -inf), which no ray overlaps, and the empty leaf reference -1.
+// arithmetic type of the intersection tests is.  Unused child slots hold a box whose two x planes are both
+// +inf, which no ray overlaps within a finite interval, and the empty leaf reference -1.
 struct alignas(16) BvhNode4 {
-  float box[BVH_WIDTH][6];   // per child: lo.xyz, hi.xyz
+  float box[BVH_WIDTH][6];   // per child: lo.x, hi.x, lo.y, hi.y, lo.z, hi.z (the two planes of an axis side by side)
   int32_t c[BVH_WIDTH];      // >= 0: inner node index; < 0: leaf reference, see LEAF_*
   int32_t pad[4];
 };
@@ -145,12 +147,13 @@ struct RayPool {
   R* color;    // 3 per ray: surface colour of the hit (k_shadow), then the colour of the ray (k_combine)
   R* mixr;     // schlick reflectance of the hit (< 0: plain sum)
   int32_t* child;      // 2 per ray: reflected, refracted child ray id (-1 = none)
-  // Child-ray slots are handed out without atomics: k_trace leaves, per block of BLOCK rays, the number of
+  // Child-ray slots are handed out without atomics: k_trace leaves, per GROUP of rays (one wave's), the number of
   // hits and an upper bound of the children they can spawn; k_scan turns the bounds into exclusive
-  // prefixes; k_spawn places its children at prefix + rank inside the block.
+  // prefixes; k_spawn places its children at prefix + rank inside the wave.
   uint32_t* blk_hits;
   uint32_t* blk_children;
   uint32_t* blk_base;
+  uint32_t* blk_top;  // per chunk of SCAN_CHUNK blocks: child total, hit total, exclusive prefix of the child totals
   int64_t capacity;
 };
 
@@ -167,6 +170,7 @@ struct FrameCtl {
   PaddedCounter holes[RT355_MAX_GEN + 1];      // slots of the generation that hold no ray (refraction that turned
                                                // out to be total internal reflection)
   PaddedCounter overflow;
+  PaddedCounter scan_ticket[RT355_MAX_GEN + 1];  // k_scan: blocks of the launch that have finished
   unsigned long long work[RT355_MAX_LAUNCH][N_WORK_COUNTERS];
 };
 

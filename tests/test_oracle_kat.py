@@ -22,7 +22,13 @@ def close(a, b, tol=EPS):
     return np.allclose(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), rtol=0, atol=tol)
 
 
-def nrm(v):
+def nrm(v, bits=64):
+    """Vector4::normalize in the precision under test: the reference normalises its test directions in f32
+    (e.g. src/cone.rs:89), sum of squares and quotients rounded to f32 one operation at a time."""
+    if bits == 32:
+        x, y, z = (np.float32(c) for c in v)
+        n = np.sqrt(np.float32(np.float32(np.float32(x * x) + np.float32(y * y)) + np.float32(z * z)))
+        return np.array([np.float32(x / n), np.float32(y / n), np.float32(z / n)], dtype=np.float32)
     v = np.asarray(v, dtype=np.float64)
     return v / np.linalg.norm(v)
 
@@ -353,9 +359,9 @@ def test_cone(oracle, bits):
     cone = Shape.Cone()
     for o, d, t0, t1 in (((0, 0, -5), (0, 0, 1), 5, 5), ((0, 0, -5), (1, 1, 1), 8.66025, 8.66025),
                          ((1, 1, -5), (-0.5, -1, 1), 4.55006, 49.44994)):
-        t, _, _ = oracle.shape_intersect(cone, o, nrm(d), bits)
-        assert len(t) == 2 and close(t, [t0, t1], 2e-3 if bits == 32 else EPS)
-    t, _, _ = oracle.shape_intersect(cone, (0, 0, -1), nrm((0, 1, 1)), bits)
+        t, _, _ = oracle.shape_intersect(cone, o, nrm(d, bits), bits)
+        assert len(t) == 2 and close(t, [t0, t1], EPS)  # the reference's own bar in f32 (src/cone.rs:91-93)
+    t, _, _ = oracle.shape_intersect(cone, (0, 0, -1), nrm((0, 1, 1), bits), bits)
     assert len(t) == 1 and close(t, [0.35355])
     capped = Shape.Cone(None, None, -0.5, 0.5, True)
     for o, d, cnt in (((0, 0, -5), (0, 1, 0), 0), ((0, 0, -0.25), (0, 1, 1), 2), ((0, 0, -0.25), (0, 1, 0), 4)):
