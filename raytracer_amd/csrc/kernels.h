@@ -44,9 +44,11 @@ template <class R> RT_FN R dot(V3<R> a, V3<R> b) { return a.x * b.x + a.y * b.y 
 template <class R> RT_FN V3<R> cross(V3<R> a, V3<R> b) {  // src/tuple.rs:42-48
   return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-template <class R> RT_FN V3<R> normalize(V3<R> a) {  // nalgebra: no zero guard
-  R n = sqrt(dot(a, a));
-  return {a.x / n, a.y / n, a.z / n};
+// nalgebra's normalize (no zero guard: a zero vector gives NaN).  The three quotients by the common norm are formed
+// with one reciprocal (within an ulp of the divisions; a division costs ten instructions in double).
+template <class R> RT_FN V3<R> normalize(V3<R> a) {
+  const R inv = R(1) / sqrt(dot(a, a));
+  return {a.x * inv, a.y * inv, a.z * inv};
 }
 template <class R> RT_FN V3<R> reflect(V3<R> v, V3<R> n) {  // src/tuple.rs:38-40
   return v - n * R(2) * dot(v, n);
@@ -900,10 +902,6 @@ RT_FN void gen_range(const FrameCtl* ctl, int gen, long long capacity, uint32_t&
   start = (uint32_t)s, count = (uint32_t)c;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Primary rays: Camera::ray_for_pixel (src/camera.rs:62-72) with the inverse hoisted out of the pixel
-// loop.  Ray i of generation 0 is pixel (x,y) of this rank's tile list: 8x8 pixel blocks per wave.
-// ------------------------------------------------------------------------------------------------
 // a / b for 0 <= a < 2^23, 0 < b <= a's range, with inv_b = 1.f / b: the float product is within one of the
 // quotient, one correction step settles it.  (A 64-bit integer division costs some 100 instructions per ray.)
 RT_FN void div_small(uint32_t a, uint32_t b, float inv_b, uint32_t& q, uint32_t& r) {
@@ -914,6 +912,38 @@ RT_FN void div_small(uint32_t a, uint32_t b, float inv_b, uint32_t& q, uint32_t&
   r = (uint32_t)rem;
 }
 
+// The hit of a ray as the trace kernels leave it: prim id (-1 = miss) and the prim's flags (kind, material,
+// reflective / transparent), so that the kernels behind need no look-up to learn what was hit.
+struct HitRec {
+  int32_t prim, flags;
+};
+template <class R> RT_FN HitRec load_hit(const RayPool<R>& pool, uint32_t r) {
+  const int2 h = *(const int2*)(pool.hit_prim + 2ull * r);
+  return HitRec{h.x, h.y};
+}
+template <class R> RT_FN void store_hit(const RayPool<R>& pool, uint32_t r, int prim, int flags) { *(int2*)(pool.hit_prim + 2ull * r) = make_int2(prim, flags); }
+
+// Origin of ray r.  The rays of generation 0 of a frame all start at the camera: their origin is not kept per ray
+// but read from the frame's view (scalar loads: the 64 rays of a wave belong to one tile, hence to one frame).
+// pool.views is null when generation 0 was loaded from caller-supplied rays.
+template <class R>
+RT_FN V3<R> view_origin(const DevView<R>& v) { return {v.inv[3], v.inv[7], v.inv[11]}; }  // inverse * point(0, 0, 0), src/camera.rs:68
+template <class R>
+RT_FN V3<R> ray_origin(const RayPool<R>& pool, uint32_t r) {
+  if (pool.views != nullptr && r < pool.n_view_rays) {  // wave-uniform: a launch works on one generation
+    uint32_t frame = 0, rest;
+    if (pool.n_views > 1) div_small(__builtin_amdgcn_readfirstlane(r), pool.rays_per_view, pool.inv_rays_per_view, frame, rest);
+    const DevView<R>* v = pool.views + __builtin_amdgcn_readfirstlane(frame);
+    cptr<R> q = (cptr<R>)(const R*)v->inv;
+    return {q[3], q[7], q[11]};
+  }
+  return ld3(pool.org + 3ull * r);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Primary rays: Camera::ray_for_pixel (src/camera.rs:62-72) with the inverse hoisted out of the pixel
+// loop.  Ray i of generation 0 is pixel (x,y) of this rank's tile list: 8x8 pixel blocks per wave.
+// ------------------------------------------------------------------------------------------------
 // tile_slot: the tile's place in this rank's output (frame-major over the batch); frame: which view.
 // Tile counts stay below 2^22 (canvas edges are at most 65536 pixels), batches below 2^6 frames; the host refuses
 // chains whose slot count would pass 2^23.
@@ -949,7 +979,7 @@ RT_FN void primary_ray(const DevCamera<R>& cam, uint32_t i, V3<R>& org, V3<R>& d
     const R world_x = v.half_width - x_offset;
     const R world_y = v.half_height - y_offset;
     const V3<R> pixel = xf_point(v.inv, mk<R>(world_x, world_y, R(-1)));
-    org = xf_point(v.inv, mk<R>(R(0), R(0), R(0)));
+    org = view_origin(v);
     dir = normalize(pixel - org);
   }
 }
@@ -958,8 +988,9 @@ RT_FN void primary_ray(const DevCamera<R>& cam, uint32_t i, V3<R>& org, V3<R>& d
 // k_trace: World::intersect + hit() for every ray of generation `gen`.  With `primary` set (generation 0
 // of a frame) the rays come from the camera instead of the pool.
 // ------------------------------------------------------------------------------------------------
+template <class R> struct HitRay;
 template <class R, bool COUNT, bool PACKET>
-RT_FN void shade_surface(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t r, bool valid, int p, int* lds, Work& wk);
+RT_FN void shade_surface(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t r, bool valid, int p, int flags, const HitRay<R>& h, int* lds, Work& wk);
 
 // One chunk of BLOCK rays of generation `gen`: World::intersect + hit() for the ray of every lane, records to
 // the pool.  With `primary` set (generation 0 of a frame) the rays come from the camera instead of the pool.
@@ -974,11 +1005,11 @@ RT_FN void trace_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* 
   const bool valid = i < count;
   const uint32_t r = start + (valid ? i : 0u);
   V3<R> o, d;
-  if (primary) {  // generation 0 of a frame: the rays are made here and kept for the later kernels
-    primary_ray(cam, r, o, d);
-    if (valid) st3(pool.org + 3ull * r, o), st3(pool.dir + 3ull * r, d);
+  if (primary) {  // generation 0 of a frame: the rays are made here; the direction is kept for the later kernels, the
+    primary_ray(cam, r, o, d);  // origin is the view's (ray_origin)
+    if (valid) st3(pool.dir + 3ull * r, d);
   } else {
-    o = ld3(pool.org + 3ull * r), d = ld3(pool.dir + 3ull * r);
+    o = ray_origin(pool, r), d = ld3(pool.dir + 3ull * r);
   }
   ClosestVis<R, COUNT> vis(sc, o, d, wk);
   const bool live = valid && !(d.x == R(0) && d.y == R(0) && d.z == R(0));
@@ -1004,16 +1035,21 @@ RT_FN void trace_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* 
   uint32_t n_child = 0;
   const bool hit = valid && vis.best_p >= 0;
   if (valid) {
-    pool.hit_prim[r] = vis.best_p;
+    store_hit(pool, r, vis.best_p, vis.best_flags);
     if (hit) {
-      pool.hit_t[r] = vis.best_t;
-      if ((vis.best_flags & PF_KIND_MASK) == RT355_SMOOTH_TRIANGLE)  // the only kind whose normal reads u, v (src/shape.rs:199-203)
-        pool.hit_uv[2ull * r] = vis.best_u, pool.hit_uv[2ull * r + 1] = vis.best_v;
+      if constexpr (!LAST) {  // the deepest generation shades its hits right here, from registers
+        pool.hit_t[r] = vis.best_t;
+        if ((vis.best_flags & PF_KIND_MASK) == RT355_SMOOTH_TRIANGLE)  // the only kind whose normal reads u, v (src/shape.rs:199-203)
+          pool.hit_uv[2ull * r] = vis.best_u, pool.hit_uv[2ull * r + 1] = vis.best_v;
+      }
       if (remaining > 0) n_child = ((vis.best_flags & PF_REFLECTIVE) ? 1u : 0u) + ((vis.best_flags & PF_TRANSPARENT) ? 1u : 0u);
     }
   }
   if constexpr (LAST) {
-    if (__ballot(hit) != 0ull) shade_surface<R, COUNT, PACKET>(sc, pool, r, hit, hit ? vis.best_p : 0, lds, wk);
+    if (__ballot(hit) != 0ull) {
+      const HitRay<R> h{o, d, vis.best_t, vis.best_u, vis.best_v};
+      shade_surface<R, COUNT, PACKET>(sc, pool, r, hit, hit ? vis.best_p : 0, vis.best_flags, h, lds, wk);
+    }
     if (valid && !hit) st3(pool.color + 3ull * r, V3<R>{R(0), R(0), R(0)});  // src/world.rs:61-63: a miss is black
   }
   // children of the wave's hits: a reflected ray per reflective hit, a refracted one per transparent hit
@@ -1063,9 +1099,9 @@ __global__ void __launch_bounds__(BLOCK, 4) k_trace_q(DevScene<R> sc, RayPool<R>
       V3<R> o, d;
       if (primary) {
         primary_ray(cam, r, o, d);
-        if (valid && writer) st3(pool.org + 3ull * r, o), st3(pool.dir + 3ull * r, d);
+        if (valid && writer) st3(pool.dir + 3ull * r, d);
       } else {
-        o = ld3(pool.org + 3ull * r), d = ld3(pool.dir + 3ull * r);
+        o = ray_origin(pool, r), d = ld3(pool.dir + 3ull * r);
       }
       ClosestVis<R, COUNT> vis(sc, o, d, wk);
       const bool live = valid && !(d.x == R(0) && d.y == R(0) && d.z == R(0));  // the same in the four lanes of a quad
@@ -1073,7 +1109,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_trace_q(DevScene<R> sc, RayPool<R>
       const bool mine = vis.quad_winner() && valid;  // one lane per ray
       const bool hit = mine && vis.best_p >= 0;
       if (mine) {
-        pool.hit_prim[r] = vis.best_p;
+        store_hit(pool, r, vis.best_p, vis.best_flags);
         if (hit) {
           pool.hit_t[r] = vis.best_t;
           if ((vis.best_flags & PF_KIND_MASK) == RT355_SMOOTH_TRIANGLE)
@@ -1281,6 +1317,28 @@ RT_FN V3<R> pattern_at(const DevMaterial<R>& m, V3<R> p) {
   }
 }
 
+// powf(x, y) of the specular term (src/material.rs:157), x > 0.  A shininess that is a whole number -- the default
+// 200.0 (src/material.rs:31-72) and every value the reference's scenes use -- is raised by repeated squaring: a
+// dozen multiplications where the general pow takes over two hundred instructions in double.  Every lane of the
+// wave takes the same path, so the general case costs nothing when no lane needs it.
+template <class R>
+RT_FN R pow_shininess(R x, R y) {
+  const bool whole = y >= R(0) && y <= R(65535) && y == floor(y);
+  R result = R(1);
+  if (whole) {
+    uint32_t n = (uint32_t)y;
+    R b = x;
+    while (n) {
+      if (n & 1u) result *= b;
+      b *= b;
+      n >>= 1;
+    }
+  } else {
+    result = pow(x, y);
+  }
+  return result;
+}
+
 // Material::lighting (src/material.rs:108-162)
 template <class R>
 RT_FN V3<R> lighting(const DevScene<R>& sc, const DevMaterial<R>& m, V3<R> point, V3<R> eyev, V3<R> normalv, bool shadowed) {
@@ -1298,7 +1356,7 @@ RT_FN V3<R> lighting(const DevScene<R>& sc, const DevMaterial<R>& m, V3<R> point
     const V3<R> rv = reflect(R(-1) * lightv, normalv);
     const R rde = dot(rv, eyev);
     if (rde > R(0)) {
-      const R factor = pow(rde, m.shininess);
+      const R factor = pow_shininess(rde, m.shininess);
       specular = li * (factor * m.specular);
     }
   }
@@ -1314,14 +1372,28 @@ template <class R>
 struct Prepared {
   V3<R> d, eyev, normalv, normalv_temp, over_point, under_point;
 };
+// a ray and its hit, as prepare() needs them
 template <class R>
-RT_FN Prepared<R> prepare(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t r, int p, int flags) {
+struct HitRay {
+  V3<R> o, d;
+  R t, u, v;
+};
+template <class R>
+RT_FN HitRay<R> load_hit_ray(const RayPool<R>& pool, uint32_t r, int flags) {
+  HitRay<R> h;
+  h.o = ray_origin(pool, r);
+  h.d = ld3(pool.dir + 3ull * r);
+  h.t = pool.hit_t[r];
+  h.u = R(0), h.v = R(0);
+  if ((flags & PF_KIND_MASK) == RT355_SMOOTH_TRIANGLE) h.u = pool.hit_uv[2ull * r], h.v = pool.hit_uv[2ull * r + 1];
+  return h;
+}
+template <class R>
+RT_FN Prepared<R> prepare(const DevScene<R>& sc, const HitRay<R>& h, int p, int flags) {
   Prepared<R> c;
-  const V3<R> o = ld3(pool.org + 3ull * r);
-  c.d = ld3(pool.dir + 3ull * r);
-  const R t = pool.hit_t[r];
-  R u = R(0), v = R(0);
-  if ((flags & PF_KIND_MASK) == RT355_SMOOTH_TRIANGLE) u = pool.hit_uv[2ull * r], v = pool.hit_uv[2ull * r + 1];
+  const V3<R> o = h.o;
+  c.d = h.d;
+  const R t = h.t, u = h.u, v = h.v;
   const V3<R> point = o + c.d * t;  // src/ray.rs:22-24
   c.eyev = R(-1) * c.d;
   c.normalv_temp = normal_at(sc, p, flags, point, u, v);
@@ -1333,30 +1405,44 @@ RT_FN Prepared<R> prepare(const DevScene<R>& sc, const RayPool<R>& pool, uint32_
   return c;
 }
 
+// The shadow ray of a point (src/world.rs:46-49): direction to the light, normalised, and the parameter limit
+// distance + EPSILON (src/world.rs:52).
+template <class R>
+RT_FN void light_ray(const DevScene<R>& sc, V3<R> point, V3<R>& ldir, R& limit) {
+  const V3<R> lv = ld3(sc.light_pos) - point;
+  const R distance = sqrt(dot(lv, lv));
+  ldir = lv * (R(1) / distance);
+  limit = distance + eps<R>();
+}
+
 // ------------------------------------------------------------------------------------------------
 // shade_surface: is_shadowed (src/world.rs:45-57) of the hit of ray r, then Material::lighting
 // (src/material.rs:108-162) with that flag; the surface colour goes to pool.color[r].  Called by all 64
 // lanes (the packet traversal needs them); `valid` marks the lanes whose ray hit prim p.
 // ------------------------------------------------------------------------------------------------
 template <class R, bool COUNT, bool PACKET>
-RT_FN void shade_surface(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t r, bool valid, int p, int* lds, Work& wk) {
-  const PrimInfo info = sc.prim_info[p];
+RT_FN void shade_surface(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t r, bool valid, int p, int flags, const HitRay<R>& h, int* lds, Work& wk) {
   Prepared<R> pc;
   pc.over_point = {R(0), R(0), R(0)};
-  if (valid) pc = prepare(sc, pool, r, p, info.flags);
-  const V3<R> lv = ld3(sc.light_pos) - pc.over_point;
-  const R distance = sqrt(dot(lv, lv));
-  const V3<R> ldir = {lv.x / distance, lv.y / distance, lv.z / distance};
-  AnyVis<R, COUNT> av(sc, pc.over_point, ldir, distance + eps<R>(), wk);
+  if (valid) pc = prepare(sc, h, p, flags);
+  V3<R> ldir;
+  R limit;
+  light_ray(sc, pc.over_point, ldir, limit);
+  AnyVis<R, COUNT> av(sc, pc.over_point, ldir, limit, wk);
+#ifndef RT355_EXP_NO_SHADOW_TRAV
   if constexpr (PACKET) {
     traverse_packet<R, COUNT>(sc, pc.over_point, ldir, valid, av, wk, lds);
   } else {
     if (valid) traverse<R, COUNT>(sc, pc.over_point, ldir, av, wk, lds);
   }
-
+#endif
   if (valid) {
-    const DevMaterial<R>& m = sc.materials[info.flags >> PF_MAT_SHIFT];
+#ifdef RT355_EXP_NO_LIGHT
+    st3(pool.color + 3ull * r, av.found ? pc.over_point : ldir);
+#else
+    const DevMaterial<R>& m = sc.materials[flags >> PF_MAT_SHIFT];
     st3(pool.color + 3ull * r, lighting(sc, m, pc.over_point, pc.eyev, pc.normalv, av.found));
+#endif
   }
 }
 
@@ -1466,13 +1552,22 @@ __global__ void __launch_bounds__(BLOCK, PACKET ? RT355_WPS_PACKET : RT355_WPS_L
   __shared__ int lds_stack[PACKET ? 1 : LDS_STACK * BLOCK];  // the packet traversal keeps its stack in a register
   int* lds = lds_stack + (PACKET ? 0 : threadIdx.x);
   Work wk;
-  for (uint32_t rbase = blockIdx.x * BLOCK; rbase < gcount; rbase += gridDim.x * BLOCK) {
+  // the hit record of the next trip is requested before this trip's work starts: its latency (a round trip to HBM)
+  // passes behind the traversal instead of in front of the next one
+  const uint32_t stride = gridDim.x * BLOCK;
+  uint32_t rbase = blockIdx.x * BLOCK;
+  HitRec next = HitRec{-1, 0};
+  if (rbase < gcount) next = load_hit(pool, start + (rbase + threadIdx.x < gcount ? rbase + threadIdx.x : 0u));
+  for (; rbase < gcount; rbase += stride) {
     const uint32_t i = rbase + threadIdx.x;
     const uint32_t r = start + (i < gcount ? i : 0u);
-    const int p_raw = pool.hit_prim[r];
-    const bool valid = i < gcount && p_raw >= 0;
+    const HitRec hit = next;
+    if (rbase + stride < gcount) next = load_hit(pool, start + (i + stride < gcount ? i + stride : 0u));
+    const bool valid = i < gcount && hit.prim >= 0;
     if (__ballot(valid) == 0ull) continue;  // wave-uniform
-    shade_surface<R, COUNT, PACKET>(sc, pool, r, valid, valid ? p_raw : 0, lds, wk);
+    HitRay<R> h{};
+    if (valid) h = load_hit_ray(pool, r, hit.flags);
+    shade_surface<R, COUNT, PACKET>(sc, pool, r, valid, valid ? hit.prim : 0, hit.flags, h, lds, wk);
   }
   flush_work<COUNT>(ctl, launch, wk);
 }
@@ -1495,22 +1590,22 @@ __global__ void __launch_bounds__(BLOCK, 4) k_shadow_q(DevScene<R> sc, RayPool<R
   for (uint32_t rbase = blockIdx.x * BLOCK; rbase < gcount; rbase += gridDim.x * BLOCK) {
     const uint32_t i = rbase + threadIdx.x;
     const uint32_t r = start + (i < gcount ? i : 0u);
-    const int p_raw = pool.hit_prim[r];
-    const bool valid = i < gcount && p_raw >= 0;
+    const HitRec hit = load_hit(pool, r);
+    const bool valid = i < gcount && hit.prim >= 0;
     const unsigned long long m = __ballot(valid);
     if (m == 0ull) continue;  // wave-uniform
-    const int p = valid ? p_raw : 0;
-    const PrimInfo info = sc.prim_info[p];
+    const int p = valid ? hit.prim : 0;
     Prepared<R> pc;
     pc.over_point = {R(0), R(0), R(0)};
     if (valid) {
-      pc = prepare(sc, pool, r, p, info.flags);
-      const V3<R> lv = ld3(sc.light_pos) - pc.over_point;  // src/world.rs:46-49
-      const R distance = sqrt(dot(lv, lv));
+      pc = prepare(sc, load_hit_ray(pool, r, hit.flags), p, hit.flags);
+      V3<R> ldir;
+      R limit;
+      light_ray(sc, pc.over_point, ldir, limit);
       R* q = s_ray + (size_t)threadIdx.x * 7;
       st3(q, pc.over_point);
-      st3(q + 3, V3<R>{lv.x / distance, lv.y / distance, lv.z / distance});
-      q[6] = distance + eps<R>();
+      st3(q + 3, ldir);
+      q[6] = limit;
       s_list[wbase + __popcll(m & lanes_below())] = (uint8_t)lane;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1533,7 +1628,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_shadow_q(DevScene<R> sc, RayPool<R
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (valid) {
-      const DevMaterial<R>& mat = sc.materials[info.flags >> PF_MAT_SHIFT];
+      const DevMaterial<R>& mat = sc.materials[hit.flags >> PF_MAT_SHIFT];
       st3(pool.color + 3ull * r, lighting(sc, mat, pc.over_point, pc.eyev, pc.normalv, s_found[threadIdx.x] != 0));
     }
   }
@@ -1549,28 +1644,31 @@ __global__ void __launch_bounds__(BLOCK, 4) k_shadow_q(DevScene<R> sc, RayPool<R
 // The 64 rays of one wave: the child rays of their hits are placed from `base` (an offset into generation gen + 1,
 // this wave's own prefix) on, reflected before refracted.  Called by every lane of the wave.
 template <class R, bool COUNT, bool PACKET>
-RT_FN void spawn_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* ctl, int gen, uint32_t start, uint32_t gcount, uint32_t i,
+RT_FN void spawn_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* ctl, int gen, uint32_t start, uint32_t gcount, uint32_t i, HitRec hit,
                        int any_transparent, int* lds, Work& wk) {
   const uint32_t child_start = start + gcount;
   const uint32_t r = start + (i < gcount ? i : 0u);
-  const int p_raw = pool.hit_prim[r];
-  const bool valid = i < gcount && p_raw >= 0;
-  if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;  // wave-uniform
+  const bool valid = i < gcount && hit.prim >= 0;
+  // hits on shapes that neither reflect nor transmit have nothing to do here
+  const bool slot_r = valid && (hit.flags & PF_REFLECTIVE);
+  const bool slot_t = valid && (hit.flags & PF_TRANSPARENT);
+  if (__builtin_amdgcn_ballot_w64(slot_r | slot_t) == 0ull) return;  // wave-uniform
   const uint32_t base = child_base(pool.blk_base, pool.blk_top, __builtin_amdgcn_readfirstlane(i) / GROUP);
-  const int p = valid ? p_raw : 0;
-  const PrimInfo info = sc.prim_info[p];
-  const bool slot_r = valid && (info.flags & PF_REFLECTIVE);
-  const bool slot_t = valid && (info.flags & PF_TRANSPARENT);
+  const int p = valid ? hit.prim : 0;
+  PrimInfo info;
+  info.flags = hit.flags, info.shape = 0;
+  HitRay<R> h{};
+  if (slot_r || slot_t) h = load_hit_ray(pool, r, hit.flags);
   R n1 = R(1), n2 = R(1);
   if (any_transparent && __ballot(slot_t) != 0ull) {  // wave-uniform
-    const V3<R> o = ld3(pool.org + 3ull * r), d = ld3(pool.dir + 3ull * r);
-    container_indices<R, COUNT, PACKET>(sc, slot_t, p, info, o, d, pool.hit_t[r], lds, wk, n1, n2);
+    if (slot_t) info.shape = sc.prim_info[p].shape;
+    container_indices<R, COUNT, PACKET>(sc, slot_t, p, info, h.o, h.d, h.t, lds, wk, n1, n2);
   }
   bool want_refr = false;
   V3<R> refl_o = {R(0), R(0), R(0)}, refl_d = refl_o, refr_o = refl_o, refr_d = refl_o;
   R rs = R(-1);
   if (slot_r || slot_t) {
-    const Prepared<R> c = prepare(sc, pool, r, p, info.flags);
+    const Prepared<R> c = prepare(sc, h, p, hit.flags);
     refl_o = c.over_point;
     refl_d = reflect(c.d, c.normalv_temp);  // un-flipped normal (src/intersection.rs:85)
     if (slot_t) {
@@ -1648,8 +1746,17 @@ __global__ void __launch_bounds__(BLOCK, PACKET ? RT355_WPS_SPAWN_PACKET : RT355
   Work wk;
   uint32_t start, gcount;
   gen_range(ctl, gen, pool.capacity, start, gcount);
-  for (uint32_t rbase = blockIdx.x * BLOCK; rbase < gcount; rbase += gridDim.x * BLOCK)
-    spawn_chunk<R, COUNT, PACKET>(sc, pool, ctl, gen, start, gcount, rbase + threadIdx.x, any_transparent, lds, wk);
+  // the next trip's hit record is requested ahead, as in k_shadow
+  const uint32_t stride = gridDim.x * BLOCK;
+  uint32_t rbase = blockIdx.x * BLOCK;
+  HitRec next = HitRec{-1, 0};
+  if (rbase < gcount) next = load_hit(pool, start + (rbase + threadIdx.x < gcount ? rbase + threadIdx.x : 0u));
+  for (; rbase < gcount; rbase += stride) {
+    const uint32_t i = rbase + threadIdx.x;
+    const HitRec hit = next;
+    if (rbase + stride < gcount) next = load_hit(pool, start + (i + stride < gcount ? i + stride : 0u));
+    spawn_chunk<R, COUNT, PACKET>(sc, pool, ctl, gen, start, gcount, i, hit, any_transparent, lds, wk);
+  }
   flush_work<COUNT>(ctl, launch, wk);
 }
 
@@ -1684,9 +1791,8 @@ RT_FN void write_pixel(const DevCamera<R>& cam, uint32_t i, int mode, float* out
 // The expression per hit is the one of src/world.rs:117-126, children first.
 template <class R, int LEVELS>
 RT_FN V3<R> ray_colour(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t r, bool has_children) {
-  const int p = pool.hit_prim[r];
-  if (p < 0) return V3<R>{R(0), R(0), R(0)};  // world.rs:61-63: a miss is black
-  const PrimInfo info = sc.prim_info[p];
+  const HitRec info = load_hit(pool, r);
+  if (info.prim < 0) return V3<R>{R(0), R(0), R(0)};  // world.rs:61-63: a miss is black
   const DevMaterial<R>& m = sc.materials[info.flags >> PF_MAT_SHIFT];
   const V3<R> surface = ld3(pool.color + 3ull * r);  // left there by k_shadow
   int32_t cr = -1, ct = -1;
@@ -1746,10 +1852,10 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_points(DevScene<R> sc, const f
   __shared__ int lds_stack[LDS_STACK * BLOCK];
   Work wk;
   const V3<R> p = {R(pts[3 * i]), R(pts[3 * i + 1]), R(pts[3 * i + 2])};
-  const V3<R> lv = ld3(sc.light_pos) - p;
-  const R distance = sqrt(dot(lv, lv));
-  const V3<R> ldir = {lv.x / distance, lv.y / distance, lv.z / distance};
-  AnyVis<R, false> av(sc, p, ldir, distance + eps<R>(), wk);
+  V3<R> ldir;
+  R limit;
+  light_ray(sc, p, ldir, limit);
+  AnyVis<R, false> av(sc, p, ldir, limit, wk);
   traverse<R, false>(sc, p, ldir, av, wk, lds_stack + threadIdx.x);
   out[i] = av.found ? 1 : 0;
 }
@@ -1762,10 +1868,10 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_points_q(DevScene<R> sc, const
   if (i >= n) return;  // whole quads leave together
   Work wk;
   const V3<R> p = {R(pts[3 * i]), R(pts[3 * i + 1]), R(pts[3 * i + 2])};
-  const V3<R> lv = ld3(sc.light_pos) - p;
-  const R distance = sqrt(dot(lv, lv));
-  const V3<R> ldir = {lv.x / distance, lv.y / distance, lv.z / distance};
-  AnyVis<R, false> av(sc, p, ldir, distance + eps<R>(), wk);
+  V3<R> ldir;
+  R limit;
+  light_ray(sc, p, ldir, limit);
+  AnyVis<R, false> av(sc, p, ldir, limit, wk);
   traverse_quad<R, false>(sc, p, ldir, av, wk, lds_stack + (threadIdx.x >> 2));
   const bool found = quad_any(av.found);
   if ((threadIdx.x & 3u) == 0) out[i] = found ? 1 : 0;
@@ -1785,7 +1891,7 @@ template <class R>
 __global__ void __launch_bounds__(256) k_export_hits(DevScene<R> sc, RayPool<R> pool, uint32_t n, double* t_out, int32_t* idx_out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const int p = pool.hit_prim[i];
+  const int p = load_hit(pool, i).prim;
   if (p < 0) {
     t_out[i] = (double)NAN;
     idx_out[i] = -1;

@@ -216,7 +216,7 @@ int dev_camera(const rt355_camera_desc* cams, int n_frames, int rank, int n_rank
   int cw = 0, chh = 0;
   if (int rc = camera_dims(cams, cw, chh)) return rc;
   if (int rc = dev_view<R>(cams, out.view)) return rc;
-  for (int f = 0; f < n_frames && n_frames > 1; ++f) {
+  for (int f = 0; f < n_frames; ++f) {
     int w2 = 0, h2 = 0;
     if (int rc = camera_dims(cams + f, w2, h2)) return rc;
     if (w2 != cw || h2 != chh) return set_err(RT355_EINVAL, "the cameras of a batch must share hsize and vsize");
@@ -252,7 +252,7 @@ int ensure_pool(rt355_ctx* c, uint64_t n_primary, bool secondary, RayPool<R>& po
   if ((rc = c->dir.ensure(cap * 3 * sizeof(R)))) return rc;
   if ((rc = c->hit_t.ensure(cap * sizeof(R)))) return rc;
   if ((rc = c->hit_uv.ensure(cap * 2 * sizeof(R)))) return rc;
-  if ((rc = c->hit_prim.ensure(cap * sizeof(int32_t)))) return rc;
+  if ((rc = c->hit_prim.ensure(cap * 2 * sizeof(int32_t)))) return rc;
   if ((rc = c->color.ensure(cap * 3 * sizeof(R)))) return rc;
   if ((rc = c->mixr.ensure(cap * sizeof(R)))) return rc;
   if ((rc = c->child.ensure(cap * 2 * sizeof(int32_t)))) return rc;
@@ -267,6 +267,7 @@ int ensure_pool(rt355_ctx* c, uint64_t n_primary, bool secondary, RayPool<R>& po
   pool.child = (int32_t*)c->child.p;
   pool.blk_hits = (uint32_t*)c->blk_hits.p, pool.blk_children = (uint32_t*)c->blk_children.p, pool.blk_base = (uint32_t*)c->blk_base.p;
   pool.blk_top = (uint32_t*)c->blk_top.p;
+  pool.views = nullptr, pool.n_view_rays = 0, pool.rays_per_view = 1, pool.n_views = 1, pool.inv_rays_per_view = 1.f;
   pool.capacity = (int64_t)cap;
   return RT355_OK;
 }
@@ -287,11 +288,12 @@ int carve_pool(rt355_ctx* c, void* base, size_t bytes, uint64_t n_primary, bool 
   *ctl = (FrameCtl*)take(sizeof(FrameCtl));
   pool.org = (R*)take(cap * 3 * sizeof(R)), pool.dir = (R*)take(cap * 3 * sizeof(R));
   pool.hit_t = (R*)take(cap * sizeof(R)), pool.hit_uv = (R*)take(cap * 2 * sizeof(R));
-  pool.hit_prim = (int32_t*)take(cap * sizeof(int32_t)), pool.color = (R*)take(cap * 3 * sizeof(R));
+  pool.hit_prim = (int32_t*)take(cap * 2 * sizeof(int32_t)), pool.color = (R*)take(cap * 3 * sizeof(R));
   pool.mixr = (R*)take(cap * sizeof(R)), pool.child = (int32_t*)take(cap * 2 * sizeof(int32_t));
   pool.blk_hits = (uint32_t*)take(nblk * sizeof(uint32_t)), pool.blk_children = (uint32_t*)take(nblk * sizeof(uint32_t));
   pool.blk_base = (uint32_t*)take(nblk * sizeof(uint32_t));
   pool.blk_top = (uint32_t*)take((scan_blocks(cap) + 1) * 3 * sizeof(uint32_t));
+  pool.views = nullptr, pool.n_view_rays = 0, pool.rays_per_view = 1, pool.n_views = 1, pool.inv_rays_per_view = 1.f;
   pool.capacity = (int64_t)cap;
   if (off > bytes)
     return set_err(RT355_ECAPACITY, "frame too large for the fixed workspace: " + std::to_string(off) + " bytes needed, " + std::to_string(bytes) +
@@ -508,10 +510,12 @@ int render_impl(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam
     if ((rc = ensure_pool<R>(c, n_primary, s->any_secondary && max_depth > 0, pool))) return rc;
     ctl = (FrameCtl*)c->ctl.p;
   }
-  if (n_frames > 1) {  // the staging buffer is free: the context's previous chain was waited for in end_frame
-    HIP_TRY(hipMemcpyAsync(c->views_dev, c->views_host, (size_t)n_frames * sizeof(DevView<R>), hipMemcpyHostToDevice, c->stream));
-    dc.views = (const DevView<R>*)c->views_dev;
-  }
+  // the views go to device memory (generation 0 reads its ray origins there, a batch all of each frame's view); the
+  // staging buffer is free: the context's previous chain was waited for in end_frame
+  HIP_TRY(hipMemcpyAsync(c->views_dev, c->views_host, (size_t)n_frames * sizeof(DevView<R>), hipMemcpyHostToDevice, c->stream));
+  dc.views = (const DevView<R>*)c->views_dev;
+  pool.views = dc.views, pool.n_view_rays = (uint32_t)n_primary, pool.rays_per_view = (uint32_t)(tpr * TILE_PIX), pool.n_views = (uint32_t)n_frames;
+  pool.inv_rays_per_view = 1.f / (float)pool.rays_per_view;
   c->throughput_chain = begin_only || n_frames > 1;
   auto t0 = std::chrono::steady_clock::now();
   LaunchLog log;

@@ -143,7 +143,7 @@ struct RayPool {
   R* dir;      // 3 per ray
   R* hit_t;    // nearest t >= 0
   R* hit_uv;   // 2 per ray (smooth triangles)
-  int32_t* hit_prim;   // prim id, -1 = miss
+  int32_t* hit_prim;   // 2 per ray: prim id (-1 = miss), the prim's flags
   R* color;    // 3 per ray: surface colour of the hit (k_shadow), then the colour of the ray (k_combine)
   R* mixr;     // schlick reflectance of the hit (< 0: plain sum)
   int32_t* child;      // 2 per ray: reflected, refracted child ray id (-1 = none)
@@ -153,6 +153,11 @@ struct RayPool {
   uint32_t* blk_hits;
   uint32_t* blk_children;
   uint32_t* blk_base;
+  // generation 0 of a frame: the rays [0, n_view_rays) start at the camera, rays_per_view of them per frame of the
+  // chain; their origin is read from views[frame] instead of org (null: every origin is in org)
+  const DevView<R>* views;
+  uint32_t n_view_rays, rays_per_view, n_views;
+  float inv_rays_per_view;
   uint32_t* blk_top;  // per chunk of SCAN_CHUNK blocks: child total, hit total, exclusive prefix of the child totals
   int64_t capacity;
 };
