@@ -159,7 +159,8 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         out = {
-            "metric": "Mrays/sec (primary+secondary) on teapot-high 1920x1080",
+            "metric": "Mrays/sec (primary+secondary) on " + ("teapot-high 1920x1080" if (args.scene, w, h) == ("north_star", 1920, 1080)
+                                                              else f"{args.scene} {w}x{h}"),
             "value": round(rays_total / elapsed / 1e6, 3),
             "unit": "Mrays/s",
             "n_gpus": world_size,
@@ -176,11 +177,13 @@ def main():
                        else f"{args.scene} {w}x{h} depth {args.depth}",
                        "shapes": world.n_shapes(), "rays_per_frame": rays_frame, "primary_rays_per_frame": primary_frame,
                        "primary_mrays_per_s": round(primary_frame / (ms * 1e-3) / 1e6, 3),
-                       "parallelism": f"tile{world_size}", "chains_in_flight": loop.K, "frames_per_chain": loop.B, "single_frame_ms": round(single_ms, 4),
+                       "parallelism": f"tile{world_size}",
+                       # bytes that arrive at rank 0 per frame in the canvas gather (float tiles; a quarter of it with as_u8)
+                       "gather_bytes_per_frame": (world_size - 1) * rd.tiles_per_rank(w, h, world_size) * rd.TILE * rd.TILE * 3 * 4, "chains_in_flight": loop.K, "frames_per_chain": loop.B, "single_frame_ms": round(single_ms, 4),
                        "bvh": scene.info()},
         }
         # --- roofline of the dominant kernel: separate frames, never inside the timed region above ----
-        peak = FP64_VALU_PEAK_TFLOPS if args.real == 64 else 2 * FP64_VALU_PEAK_TFLOPS
+        peak64, peak32 = FP64_VALU_PEAK_TFLOPS, 2 * FP64_VALU_PEAK_TFLOPS
         dev.set_timing(True)
         n_prof = 5
         acc = None
@@ -192,56 +195,76 @@ def main():
             acc = ms_l if acc is None else acc + ms_l
         dev.set_timing(False)
         ms_l = acc / n_prof
-        dev.set_counting(True)
-        rd.render_tiles_chain(scene, [cam] * loop.B, args.depth, rank, world_size, chain_out, st)
-        dev.set_counting(False)
-        flops = np.array(st.launch_flops[: st.n_launch], dtype=np.float64)
-        box_flops = 24.0 * np.array(st.launch_box_tests[: st.n_launch], dtype=np.float64)  # box tests run in f32
-        maxbox = list(st.launch_max_box_tests[: st.n_launch])
-        rays_gen = [int(x) for x in st.radiance_rays]
-        hits_gen = [int(x) for x in st.hits]
         kinds = list(st.launch_kind[: st.n_launch])
         gens = list(st.launch_gen[: st.n_launch])
+
+        def counted(mode):
+            dev.set_counting(mode)
+            try:
+                rd.render_tiles_chain(scene, [cam] * loop.B, args.depth, rank, world_size, chain_out, st)
+            finally:
+                dev.set_counting(0)
+            assert list(st.launch_kind[: st.n_launch]) == kinds and list(st.launch_gen[: st.n_launch]) == gens
+            fl = np.array(st.launch_flops[: st.n_launch], dtype=np.float64)
+            box = 24.0 * np.array(st.launch_box_tests[: st.n_launch], dtype=np.float64)  # the box tests run in f32
+            return fl - box, box, list(st.launch_max_box_tests[: st.n_launch])
+
+        # The numerator is the PER-RAY count: every generation traced one ray per lane over the same BVH, so a ray is
+        # charged for the boxes and primitives its own path reaches and not for what the other 63 rays of a packet
+        # made its wave visit.  The count of the kernels as they run (packets) is reported beside it.
+        f64_ray, f32_ray, maxbox = counted(2)
+        f64_run, f32_run, _ = counted(1)
+        rays_gen = [int(x) for x in st.radiance_rays]
+        hits_gen = [int(x) for x in st.hits]
         k = int(np.argmax(ms_l))
-        achieved = flops[k] / (ms_l[k] * 1e-3) / 1e12
+        sec_k = ms_l[k] * 1e-3
+        achieved = f64_ray[k] / sec_k / 1e12
         kernel_name = f"{KIND_NAME.get(kinds[k], '?')} generation {gens[k]}"
         headline = (args.scene, w, h, args.depth, args.real, world_size) == ("north_star", 1920, 1080, 5, 64, 1)
         counters = _measured_counters(kernel_name, loop.B) if headline else None
         traffic = int(counters["hbm_bytes"]) if counters else None
+        in_f64 = args.real == 64
         out["roofline"] = {
-            "bound": "valu_fp64" if args.real == 64 else "valu_fp32",
+            # arithmetic of the path in the graded precision against that precision's vector peak; the conservative
+            # single-precision box tests are reported against the single-precision peak beside it, never summed in
+            "bound": "valu_fp64" if in_f64 else "valu_fp32",
             "kernel": kernel_name,
-            "achieved": round(achieved, 4),
-            "peak": peak,
+            "achieved": round(achieved if in_f64 else (f64_ray[k] + f32_ray[k]) / sec_k / 1e12, 4),
+            "peak": peak64 if in_f64 else peak32,
             "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 5),
+            "frac": round((achieved / peak64) if in_f64 else (f64_ray[k] + f32_ray[k]) / sec_k / 1e12 / peak32, 5),
             "traffic": traffic,
-            "flops_per_launch": float(flops[k]),
-            # the algorithmic count charges every unit of work to the FP64 peak; the box tests (24 FLOP each) run
-            # in single precision on purpose, so this is how much of the count is really f64 work
-            "flops_per_launch_f64_part": float(flops[k] - box_flops[k]),
-            "flops_per_launch_f32_boxes": float(box_flops[k]),
+            "count": "per ray: SURVEY-style algorithmic FLOPs of the boxes / primitives each ray's own BVH path tests (counting mode 2)",
+            "flops_per_launch": float(f64_ray[k]),
+            "f32_box_tests": {"flops_per_launch": float(f32_ray[k]), "achieved": round(float(f32_ray[k] / sec_k / 1e12), 4), "peak": peak32,
+                              "frac": round(float(f32_ray[k] / sec_k / 1e12 / peak32), 5)},
+            "as_executed_by_packets": {"flops_per_launch_f64": float(f64_run[k]), "flops_per_launch_f32_boxes": float(f32_run[k]),
+                                        "note": "every live lane charged for every node and triangle its wave visits; not used for frac"},
             "launch_ms": round(float(ms_l[k]), 4),
             # a launch works on a chain of this many frames: the per-launch figures above and below are per chain
             "frames_per_launch": loop.B,
-            "frame_flops": float(flops.sum() / loop.B),
-            "frame_flops_f64_part": float((flops - box_flops).sum() / loop.B),
+            "frame_flops_f64": float(f64_ray.sum() / loop.B),
+            "frame_flops_f32_boxes": float(f32_ray.sum() / loop.B),
             "frame_kernel_ms": round(float(ms_l.sum() / loop.B), 4),
             # whole frame against the peak, by the wall time of the timed region (chains overlap)
-            "frame_frac": round(float(flops.sum() / loop.B / (ms * 1e-3) / 1e12 / peak), 5),
+            "frame_frac": round(float(f64_ray.sum() / loop.B / (ms * 1e-3) / 1e12 / peak64), 5) if in_f64 else
+                          round(float((f64_ray + f32_ray).sum() / loop.B / (ms * 1e-3) / 1e12 / peak32), 5),
             "launches": [{"kernel": KIND_NAME.get(kinds[i], "?"), "gen": gens[i], "ms": round(float(ms_l[i]), 4),
-                          "gflop": round(float(flops[i]) / 1e9, 4), "gflop_f32_boxes": round(float(box_flops[i]) / 1e9, 4),
-                          "max_box_tests_one_lane": int(maxbox[i])} for i in range(len(kinds))],
+                          "gflop_f64": round(float(f64_ray[i]) / 1e9, 4), "gflop_f32_boxes": round(float(f32_ray[i]) / 1e9, 4),
+                          "gflop_f64_packets": round(float(f64_run[i]) / 1e9, 4), "gflop_f32_boxes_packets": round(float(f32_run[i]) / 1e9, 4),
+                          "max_box_tests_one_ray": int(maxbox[i])} for i in range(len(kinds))],
             "rays_by_generation": rays_gen, "hits_by_generation": hits_gen,
         }
         if counters:
-            gbs = traffic / (ms_l[k] * 1e-3) / 1e9
+            gbs = traffic / sec_k / 1e9
             out["roofline"]["hbm"] = {"achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4)}
             # the same launch by the hardware's own count of FP64 vector instructions: 64 x (ADD + MUL + TRANS + 2 FMA)
             # is an upper bound on executed FP64 FLOPs (idle lanes included), from the committed PMC passes
             out["roofline"]["counters"] = {k2: counters[k2] for k2 in ("fp64_flops_upper_bound", "lane_utilisation", "wait_any_frac",
-                                                                       "valu_active_frac", "l2_hit_rate", "source") if k2 in counters}
-            out["roofline"]["counters"]["fp64_frac_upper_bound"] = round(counters["fp64_flops_upper_bound"] / (ms_l[k] * 1e-3) / 1e12 / peak, 5)
+                                                                       "valu_active_frac", "l2_hit_rate", "valu_instructions", "source") if k2 in counters}
+            out["roofline"]["counters"]["fp64_frac_upper_bound"] = round(counters["fp64_flops_upper_bound"] / sec_k / 1e12 / peak64, 5)
+        if world_size == 1:
+            out["config"].update(_boundary_call(dev, scene, cam, args.depth, w, h))
         if world_size == 1 and headline and not args.no_extra:
             out["config"]["also"] = _other_sizes(dev, scene, args)
         if not args.no_cpu_baseline and world_size == 1:
@@ -250,6 +273,30 @@ def main():
     if world_size > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _boundary_call(dev, scene, cam, depth, w, h):
+    """The drop-in call itself, one frame in and one host canvas out like Camera::render (src/camera.rs:74-88):
+    rt355_render into pinned host memory (rt355_host_alloc) and rt355_render_u8, wall time per call."""
+    lib = dev.lib
+    cd = cam.to_desc()
+    n = w * h * 3
+    out = {}
+    for name, fn, nbytes in (("boundary_call_ms", lib.rt355_render, n * 4), ("boundary_call_u8_ms", lib.rt355_render_u8, n)):
+        buf = lib.rt355_host_alloc(nbytes)
+        if not buf:
+            continue
+        try:
+            for _ in range(2):
+                _abi.check(fn(dev.handle, scene.handle, C.byref(cd), depth, C.c_void_p(buf), None))
+            t0 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                _abi.check(fn(dev.handle, scene.handle, C.byref(cd), depth, C.c_void_p(buf), None))
+            out[name] = round((time.perf_counter() - t0) / reps * 1e3, 4)
+        finally:
+            lib.rt355_host_free(C.c_void_p(buf))
+    return out
 
 
 def _other_sizes(dev, scene, args):
@@ -286,12 +333,12 @@ def _measured_counters(kernel_name, frames_per_chain):
     passes (a bench run cannot collect hardware counters itself).  None when there is no such measurement or
     when it was taken on other kernel sources than the ones in the tree or on chains of another length."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_counters.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r03_counters.json")) as fh:
             doc = json.load(fh)
         if doc.get("source_hash") != source_hash() or doc.get("frames_per_chain") != frames_per_chain:
             return None
         c = dict(doc["launches"][kernel_name])
-        c["source"] = "profiles/r02_counters.json"
+        c["source"] = "profiles/r03_counters.json"
         return c
     except (OSError, KeyError, ValueError):
         return None

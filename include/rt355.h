@@ -101,7 +101,7 @@ enum rt355_launch_kind {
   RT355_K_COMBINE = 3,   /* Phong lighting + child colours folded into their parent; generation 0
                             writes the canvas */
   RT355_K_SPAWN = 5,     /* n1 / n2, reflect / refract / schlick: writes the rays of the next generation */
-  RT355_K_SCAN = 6       /* prefix sums of the child-ray slots of one generation (one block) */
+  RT355_K_SCAN = 6       /* prefix sums of the child-ray slots of one generation */
 };
 
 /* Per-frame statistics.  Ray counts are always filled.  Work counters (box_tests ... flops) are
@@ -152,7 +152,11 @@ int rt355_ctx_set_pool(rt355_ctx*, double rays_per_pixel);
  * truncated cones; beyond that cones live in the BVH and a hit of this kind is found only if the ray
  * also passes the cone's bounding box.  Applies to scenes uploaded afterwards. */
 int rt355_ctx_set_exact_cones(rt355_ctx*, int mode);
-int rt355_ctx_set_counting(rt355_ctx*, int on);
+/* Counting mode.  0: off.  1: the frame's own kernels, instrumented (what the launches really tested: in a wave-packet
+ * traversal every live lane is charged for every node and triangle its wave visits).  2: PER RAY -- every generation is
+ * traced one ray per lane, so a ray is charged only for the boxes and primitives of the nodes its own path through the
+ * BVH reaches; the count a roofline numerator is made from, since it does not reward the union work of packets. */
+int rt355_ctx_set_counting(rt355_ctx*, int mode);
 int rt355_ctx_set_timing(rt355_ctx*, int on);
 
 /* Replaces the per-ray work the reference redoes for every shape and every ray
@@ -190,11 +194,13 @@ void rt355_host_free(void*);
 int rt355_render_device(rt355_ctx*, const rt355_scene*, const rt355_camera_desc* cam, int max_depth,
                         float* rgb_out_dev, rt355_stats* stats /* nullable */);
 
-/* rt355_render_device for callers that cannot allocate device memory (code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  The frame's ray
+/* rt355_render_device for callers that cannot allocate device memory (tight serving loops, harnesses that forbid
+ * hipMalloc).  It has no counterpart in the reference.  It allocates nothing and is synchronous with respect to the
+ * host: it waits for the frame and reads its statistics back, so it is not a call to make while a stream is being
+ * captured into a HIP graph.  The frame's ray
  * pool and control block live in a fixed workspace of RT355_NOALLOC_BYTES inside the library (one copy per
  * GPU, held until the process ends) instead of the context's growable buffers: the call allocates and frees
- * nothing.  A frame that needs more -- (tiles x 1024 primary rays) x pool factor x ~118 bytes in f64, ~66 in
+ * nothing.  A frame that needs more -- (tiles x 1024 primary rays) x pool factor x ~122 bytes in f64, ~70 in
  * f32, i.e. about 320x200 at the default factor 8 in f64 -- is refused with RT355_ECAPACITY before any launch.
  * Every call on a GPU shares that GPU's workspace: calls that overlap on one GPU (two contexts, two threads)
  * race; the workspace keeps the last frame's contents, what must start at zero is cleared by the call itself.

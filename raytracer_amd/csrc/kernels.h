@@ -160,6 +160,10 @@ RT_FN void prim_hits(const DevScene<R>& sc, int p, int flags, V3<R> wo, V3<R> wd
   if constexpr (COUNT) wk.prim[kind]++;
   V3<R> o = wo, d = wd;
   R ext_min = R(0), ext_max = R(0);
+  // the w term of inverse * direction, m[k][3] * 0.0 (src/ray.rs:35): a signed zero, -0.0 where the inverse's
+  // translation entry is negative.  It decides nothing but the sign of a zero direction component, which the cube's
+  // slab test tells apart (below).  The identity's entries are +0.0.
+  V3<R> w_term = {R(0), R(0), R(0)};
   if (!(flags & PF_IDENTITY) || kind == RT355_CYLINDER || kind == RT355_CONE) {
     DevXform<R> X;
     if constexpr (UNIFORM) X = load_uniform(&sc.xform[p]); else X = sc.xform[p];
@@ -167,6 +171,7 @@ RT_FN void prim_hits(const DevScene<R>& sc, int p, int flags, V3<R> wo, V3<R> wd
     if (!(flags & PF_IDENTITY)) {
       o = xf_point(X.r, wo);
       d = xf_vec(X.r, wd);
+      w_term = {X.r[3] * R(0), X.r[7] * R(0), X.r[11] * R(0)};
       if constexpr (COUNT) wk.xf++;
     }
   }
@@ -197,10 +202,9 @@ RT_FN void prim_hits(const DevScene<R>& sc, int p, int flags, V3<R> wo, V3<R> wd
       // The branch `direction >= 0` is also taken by -0.0, whose quotients then come out with the signs
       // swapped: a ray with a zero direction component misses or hits a slab it lies inside depending on the
       // SIGN of that zero.  In the reference that sign is whatever the 4-term row sums of inverse * direction
-      // leave (the w term m[k][3] * 0.0 is +0.0 for every transformation without a negative inverse
-      // translation, which makes the sum +0.0); here the rows have three terms and the identity skips them,
-      // so the zero is made +0.0 explicitly.
-      d = V3<R>{d.x + R(0), d.y + R(0), d.z + R(0)};
+      // leave; the rows here have three terms (none for the identity), so the fourth, a signed zero, is added now:
+      // -0.0 survives only when all four terms are -0.0, as in the reference.
+      d = d + w_term;
       R t0x, t1x, t0y, t1y, t0z, t1z;
       if (d.x >= R(0)) { t0x = (R(-1) - o.x) / d.x; t1x = (R(1) - o.x) / d.x; } else { t1x = (R(-1) - o.x) / d.x; t0x = (R(1) - o.x) / d.x; }
       if (d.y >= R(0)) { t0y = (R(-1) - o.y) / d.y; t1y = (R(1) - o.y) / d.y; } else { t1y = (R(-1) - o.y) / d.y; t0y = (R(1) - o.y) / d.y; }

@@ -43,7 +43,8 @@ const double F_KIND[8] = {28 /*sphere*/, 4 /*plane*/, 20 /*cube*/, 50 /*cylinder
 const double F_SHADE = 190, F_REFLECT = 30, F_REFRACT = 35, F_SCHLICK = 25;
 
 // Fixed workspace of rt355_render_device_noalloc: the frame's ray pool and control block for callers that may
-// not allocate (HIP graph capture, serving loops).  One copy per GPU the library runs on, held until the
+// not allocate (serving loops, harnesses that forbid it).  The call allocates nothing; it is synchronous with respect
+// to the host (it waits for the frame), so it is not a call to make under stream capture.  One copy per GPU the library runs on, held until the
 // process ends.  In host code the array's name is only a handle: the device address is asked for once per
 // device (scratch_address) and everything on the host side goes through that pointer.
 static __device__ __align__(256) unsigned char scratch[RT355_NOALLOC_BYTES];
@@ -104,7 +105,8 @@ struct rt355_ctx {
   hipStream_t side = nullptr;  // shadow launches, beside the trace / spawn chain
   hipEvent_t ev_traced[RT355_MAX_GEN] = {}, ev_side_done = nullptr;
   double pool_factor = 8.0;
-  bool counting = false, timing = false;
+  int counting = 0;  // 0 off, 1 the frame's own kernels instrumented, 2 per ray (every generation one ray per lane)
+  bool timing = false;
   int exact_cones = 0;
   // Generations 0..packet_gens-1 use the wave-packet traversal, the later ones one lane per ray.  -1: chosen per scene --
   // every generation when few prims can spawn secondary rays (their reflections and refractions leave a handful of
@@ -124,6 +126,7 @@ struct rt355_ctx {
   void* views_dev = nullptr;   // the views of a batch of frames (RT355_MAX_BATCH x DevView<double>), read by generation 0
   void* views_host = nullptr;  // pinned staging of the same
   void* fixed_scratch = nullptr;  // this device's copy of the fixed workspace (rt355_render_device_noalloc)
+  std::string fixed_scratch_error;  // why it is null, if it is
   // a frame begun with rt355_render_tiles_begin and not yet ended: its launches are queued, nothing was waited for
   bool pending = false;
   LaunchLog pending_log;
@@ -312,7 +315,7 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, FrameC
   // Packets do more arithmetic per ray and stall less: best for the rate of chains that overlap (begun, not waited
   // for) or carry several frames; one frame alone, whose every kernel ends on its slowest wave, is done soonest with
   // packets for generations 0 and 1 only.
-  const int packet_gens = c->packet_gens >= 0 ? c->packet_gens : s->n_secondary_prims > PACKET_SECONDARY_PRIMS ? 1 : c->throughput_chain ? (int)RT355_MAX_GEN : 2;
+  const int packet_gens = c->counting == 2 ? 0 : c->packet_gens >= 0 ? c->packet_gens : s->n_secondary_prims > PACKET_SECONDARY_PRIMS ? 1 : c->throughput_chain ? (int)RT355_MAX_GEN : 2;
   hipLaunchKernelGGL(k_reset_ctl, dim3(1), dim3(256), 0, c->stream, ctl, n_primary);
   const int depth = s->any_secondary ? max_depth : 0;  // no reflective / transparent material: one generation
   const int block = BLOCK;
@@ -739,10 +742,10 @@ int rt355_ctx_create_ex(rt355_ctx** out, int device_id, int real_bits, int flags
     rt355_ctx_destroy(c);
     return set_err(RT355_ENOMEM, "allocation of the batch view table failed");
   }
-  if (int rc = scratch_address(device_id, &c->fixed_scratch)) {  // the device is current here
-    rt355_ctx_destroy(c);
-    return rc;
-  }
+  // the fixed workspace of rt355_render_device_noalloc: looked up here, where the device is current and a set-up call may
+  // still fail softly.  Without it (a device id beyond the table, a failed look-up) the context works for every
+  // other entry point and the no-allocation one reports the reason.
+  if (scratch_address(device_id, &c->fixed_scratch) != RT355_OK) c->fixed_scratch = nullptr, c->fixed_scratch_error = g_err;
   if (const char* e = getenv("RT355_PACKET_GENS")) c->packet_gens = std::max(0, std::min((int)RT355_MAX_GEN, atoi(e)));
   if (const char* e = getenv("RT355_COMBINE_LEVELS")) c->combine_levels = std::max(0, std::min(3, atoi(e)));
   if (const char* e = getenv("RT355_SHADOW_LAG")) c->shadow_lag = std::max(0, atoi(e));
@@ -781,9 +784,9 @@ int rt355_ctx_set_exact_cones(rt355_ctx* c, int mode) {
   c->exact_cones = mode;
   return RT355_OK;
 }
-int rt355_ctx_set_counting(rt355_ctx* c, int on) {
-  if (!c) return set_err(RT355_EINVAL, "null context");
-  c->counting = on != 0;
+int rt355_ctx_set_counting(rt355_ctx* c, int mode) {
+  if (!c || mode < 0 || mode > 2) return set_err(RT355_EINVAL, "counting mode must be 0, 1 or 2");
+  c->counting = mode;
   return RT355_OK;
 }
 int rt355_ctx_set_timing(rt355_ctx* c, int on) {
@@ -962,7 +965,7 @@ int rt355_render_device_noalloc(rt355_ctx* c, const rt355_scene* s, const rt355_
   int rc = check_render_args(c, s, cam, max_depth);
   if (rc) return rc;
   if (!rgb_out_dev) return set_err(RT355_EINVAL, "null output");
-  if (!c->fixed_scratch) return set_err(RT355_EHIP, "fixed workspace address unknown");
+  if (!c->fixed_scratch) return set_err(RT355_EHIP, "fixed workspace unavailable on this context: " + c->fixed_scratch_error);
   // frames larger than the workspace are refused by carve_pool, before anything is launched
   return c->real_bits == 32 ? render_impl<float>(c, s, cam, max_depth, 0, 1, OUT_ROWMAJOR, rgb_out_dev, stats, true)
                             : render_impl<double>(c, s, cam, max_depth, 0, 1, OUT_ROWMAJOR, rgb_out_dev, stats, true);
@@ -1016,10 +1019,10 @@ int rt355_is_shadowed(rt355_ctx* c, const rt355_scene* s, const float* points, s
   if (!s || (!points && n) || (!out && n)) return set_err(RT355_EINVAL, "null argument");
   if (s->device != c->device || s->real_bits != c->real_bits) return set_err(RT355_EINVAL, "scene was uploaded on another device or for another precision");
   if (n == 0) return RT355_OK;
+  if (n >= 0x3fffffffull) return set_err(RT355_EINVAL, "too many points in one call");  // before anything is allocated or copied
   if ((rc = c->io_in.ensure(n * 3 * sizeof(float)))) return rc;
   if ((rc = c->io_out.ensure(n))) return rc;
   HIP_TRY(hipMemcpyAsync(c->io_in.p, points, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  if (n >= 0x3fffffffull) return set_err(RT355_EINVAL, "too many points in one call");
   const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK), grid_q = (unsigned)((n + QUADS - 1) / QUADS);
   if (c->quad & 2) {  // the traversal the frame's shadow launches use
     if (c->real_bits == 32)

@@ -182,6 +182,9 @@ int rt355_multi_render_batch(rt355_multi* m, const rt355_camera_desc* cam, int n
   const size_t canvas_floats = (size_t)(int)cam->hsize * (size_t)(int)cam->vsize * 3 * (size_t)n_frames;
   auto t0 = std::chrono::steady_clock::now();
   if (count > m->tiles_floats || canvas_floats > m->canvas_floats) {  // first frame of a larger size
+    // the recorded sizes describe the buffers only once every allocation has succeeded: a failure below leaves them
+    // at zero, so the next call allocates again instead of rendering into a freed or null buffer
+    m->tiles_floats = 0, m->canvas_floats = 0;
     for (int d = 0; d < m->n; ++d) {
       MHIP(hipSetDevice(m->dev[d]));
       if (d > 0) {
@@ -218,15 +221,23 @@ int rt355_multi_render_batch(rt355_multi* m, const rt355_camera_desc* cam, int n
   // gather to device 0
   if (m->n > 1) {
     if (!m->comm.empty()) {
+      // Nothing returns between GroupStart and GroupEnd: a group left open would poison every later collective on
+      // these communicators.  A failure inside the group is recorded and reported behind GroupEnd.
       ncclResult_t r = g_rccl.GroupStart();
-      for (int d = 1; d < m->n && r == ncclSuccess; ++d) {
-        MHIP(hipSetDevice(m->dev[d]));
-        r = g_rccl.Send(m->tiles[d], count, ncclFloat, 0, m->comm[d], m->stream[d]);
+      hipError_t he = hipSuccess;
+      if (r == ncclSuccess) {
+        for (int d = 1; d < m->n && r == ncclSuccess && he == hipSuccess; ++d) {
+          he = hipSetDevice(m->dev[d]);
+          if (he == hipSuccess) r = g_rccl.Send(m->tiles[d], count, ncclFloat, 0, m->comm[d], m->stream[d]);
+        }
+        if (he == hipSuccess) he = hipSetDevice(m->dev[0]);
+        for (int d = 1; d < m->n && r == ncclSuccess && he == hipSuccess; ++d)
+          r = g_rccl.Recv(m->gathered + (size_t)d * count, count, ncclFloat, d, m->comm[0], m->stream[0]);
+        const ncclResult_t r2 = g_rccl.GroupEnd();
+        if (r == ncclSuccess) r = r2;
       }
-      MHIP(hipSetDevice(m->dev[0]));
-      for (int d = 1; d < m->n && r == ncclSuccess; ++d) r = g_rccl.Recv(m->gathered + (size_t)d * count, count, ncclFloat, d, m->comm[0], m->stream[0]);
-      ncclResult_t r2 = g_rccl.GroupEnd();
-      if (r != ncclSuccess || r2 != ncclSuccess) return fail(RT355_EHIP, std::string("RCCL gather: ") + g_rccl.GetErrorString(r != ncclSuccess ? r : r2));
+      if (he != hipSuccess) return fail(RT355_EHIP, std::string("RCCL gather: hipSetDevice: ") + hipGetErrorString(he));
+      if (r != ncclSuccess) return fail(RT355_EHIP, std::string("RCCL gather: ") + g_rccl.GetErrorString(r));
       for (int d = 0; d < m->n; ++d) {
         MHIP(hipSetDevice(m->dev[d]));
         MHIP(hipStreamSynchronize(m->stream[d]));

@@ -66,8 +66,14 @@ bool affine_inverse(const float* m, double inv[12]) {
     inv[row * 4 + 2] = r[row * 3 + 2];
     inv[row * 4 + 3] = -(r[row * 3 + 0] * tx + r[row * 3 + 1] * ty + r[row * 3 + 2] * tz);
   }
-  for (int k = 0; k < 12; ++k)
+  // The SIGN of a zero entry reaches the cube's slab test through the zero components of inverse * direction
+  // (prim_hits).  A general 4x4 inverse by cofactors (what the reference computes, src/ray.rs:34-35) leaves a zero
+  // entry as a sum of products of mixed signs, +0.0, times 1 / det: every zero carries the determinant's sign.  The
+  // closed forms above leave zeros of either sign, so they are set here.
+  for (int k = 0; k < 12; ++k) {
     if (!std::isfinite(inv[k])) return false;
+    if (inv[k] == 0.0) inv[k] = std::copysign(0.0, det);
+  }
   return true;
 }
 

@@ -307,8 +307,9 @@ class Device:
     def set_exact_cones(self, mode):
         _abi.check(self.lib.rt355_ctx_set_exact_cones(self.handle, int(mode)))
 
-    def set_counting(self, on):
-        _abi.check(self.lib.rt355_ctx_set_counting(self.handle, int(bool(on))))
+    def set_counting(self, mode):
+        """0 / False: off; 1 / True: the frame's kernels instrumented; 2: per-ray count (one ray per lane throughout)."""
+        _abi.check(self.lib.rt355_ctx_set_counting(self.handle, int(mode)))
 
     def set_timing(self, on):
         _abi.check(self.lib.rt355_ctx_set_timing(self.handle, int(bool(on))))

@@ -113,7 +113,7 @@ extern "C" {
     pub fn rt355_ctx_destroy(ctx: *mut rt355_ctx);
     pub fn rt355_ctx_set_pool(ctx: *mut rt355_ctx, rays_per_pixel: f64) -> c_int;
     pub fn rt355_ctx_set_exact_cones(ctx: *mut rt355_ctx, mode: c_int) -> c_int;
-    pub fn rt355_ctx_set_counting(ctx: *mut rt355_ctx, on: c_int) -> c_int;
+    pub fn rt355_ctx_set_counting(ctx: *mut rt355_ctx, mode: c_int) -> c_int;
     pub fn rt355_ctx_set_timing(ctx: *mut rt355_ctx, on: c_int) -> c_int;
     pub fn rt355_scene_upload(ctx: *mut rt355_ctx, shapes: *const rt355_shape_desc, n_shapes: usize,
                               light: *const rt355_light_desc, out: *mut *mut rt355_scene) -> c_int;

@@ -435,3 +435,32 @@ class _RawCamera:
         d.hsize, d.vsize, d.fov = self._hs, self._vs, 1.0
         d.transform[:] = mx.to_abi(mx.identity()).tolist()
         return d
+
+
+@pytest.mark.parametrize("real_bits", [64, 32])
+def test_cube_slab_test_sees_the_sign_of_a_zero_direction(oracle, real_bits):
+    """src/shape.rs:455-466 branches on `direction >= 0`, which -0.0 passes: the quotients then come out with swapped
+    signs and a ray lying INSIDE that slab misses the cube.  The sign of a zero component after inverse * direction is
+    that of the four-term row sum (src/ray.rs:35), whose w term m[k][3] * 0.0 is -0.0 for a cube moved to a positive
+    position.  Device and oracle must agree ray by ray, for both signs of the translation and of the zero."""
+    worlds = []
+    for tx in (3.0, -3.0, 0.0):
+        cube = Shape.Cube(mx.translation(tx, 0.0, 0.0)) if tx else Shape.Cube()
+        worlds.append((tx, World(None, [cube])))
+    dirs = [(-0.0, -1.0, -1.0), (0.0, -1.0, -1.0), (-0.0, 1.0, -1.0), (-0.0, -1.0, 1.0), (0.0, 1.0, 1.0)]
+    dev = Device.get(0, real_bits)
+    n_miss = n_hit = 0
+    for tx, world in worlds:
+        rr = np.array([[tx + 0.5, -5.0 * d[1], -5.0 * d[2], d[0], d[1] / math.sqrt(2), d[2] / math.sqrt(2)] for d in dirs], dtype=np.float32)
+        scene = dev.upload(world)
+        t_dev, i_dev = scene.trace(rr)
+        scene.close()
+        t_or, i_or, _ = oracle.hit(world, rr, real_bits)
+        for k in range(len(dirs)):
+            assert (i_dev[k] >= 0) == (i_or[k] >= 0), (tx, dirs[k], t_dev[k], t_or[k])
+            if i_or[k] >= 0:
+                assert abs(t_dev[k] - t_or[k]) <= 1e-3
+                n_hit += 1
+            else:
+                n_miss += 1
+    assert n_miss > 0 and n_hit > 0  # both outcomes occur: the sign of the zero decides

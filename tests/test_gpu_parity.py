@@ -428,6 +428,30 @@ def test_counting_mode_reports_work(dev):
     assert all(st.launch_ms[i] >= 0 for i in range(st.n_launch))
 
 
+def test_per_ray_count_does_not_exceed_the_packet_count(dev):
+    """Counting mode 2 traces every generation one ray per lane: the image is the same, the rays and hits are the same,
+    and a ray is charged only for what its own path through the BVH tests -- never more than what the wave packets
+    of the default plan charge their lanes."""
+    world, cam = scenes.north_star(160, 90, mesh="teapot-low.obj")
+    scene = dev.upload(world)
+    a, b = Stats(), Stats()
+    try:
+        dev.set_counting(1)
+        img_a = scene.render(cam, 5, a).pixels.copy()
+        dev.set_counting(2)
+        img_b = scene.render(cam, 5, b).pixels.copy()
+    finally:
+        dev.set_counting(0)
+    scene.close()
+    assert np.array_equal(img_a, img_b)
+    assert list(a.radiance_rays) == list(b.radiance_rays) and list(a.hits) == list(b.hits)
+    box_a, box_b = sum(a.launch_box_tests[: a.n_launch]), sum(b.launch_box_tests[: b.n_launch])
+    prim_a, prim_b = sum(a.launch_prim_tests[: a.n_launch]), sum(b.launch_prim_tests[: b.n_launch])
+    assert 0 < box_b <= box_a and 0 < prim_b <= prim_a
+    with pytest.raises(Exception):
+        dev.set_counting(3)
+
+
 def test_deepest_recursion_with_instrumentation(dev, oracle):
     """max_depth 7 is the limit of the interface: every generation, with and without per-launch
     instrumentation (which also moves the shadow launches from the side stream to the main one)."""
