@@ -993,8 +993,9 @@ RT_FN void primary_ray(const DevCamera<R>& cam, uint32_t i, V3<R>& org, V3<R>& d
 // of a frame) the rays come from the camera instead of the pool.
 // ------------------------------------------------------------------------------------------------
 template <class R> struct HitRay;
-template <class R, bool COUNT, bool PACKET>
-RT_FN void shade_surface(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t r, bool valid, int p, int flags, const HitRay<R>& h, int* lds, Work& wk);
+struct SpawnAt;
+template <class R, bool COUNT, bool PACKET, bool SPAWN>
+RT_FN void shade_surface(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t r, bool valid, int p, int flags, const HitRay<R>& h, int* lds, Work& wk, const SpawnAt* at);
 
 // One chunk of BLOCK rays of generation `gen`: World::intersect + hit() for the ray of every lane, records to
 // the pool.  With `primary` set (generation 0 of a frame) the rays come from the camera instead of the pool.
@@ -1052,7 +1053,7 @@ RT_FN void trace_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* 
   if constexpr (LAST) {
     if (__ballot(hit) != 0ull) {
       const HitRay<R> h{o, d, vis.best_t, vis.best_u, vis.best_v};
-      shade_surface<R, COUNT, PACKET>(sc, pool, r, hit, hit ? vis.best_p : 0, vis.best_flags, h, lds, wk);
+      shade_surface<R, COUNT, PACKET, false>(sc, pool, r, hit, hit ? vis.best_p : 0, vis.best_flags, h, lds, wk, nullptr);
     }
     if (valid && !hit) st3(pool.color + 3ull * r, V3<R>{R(0), R(0), R(0)});  // src/world.rs:61-63: a miss is black
   }
@@ -1419,16 +1420,50 @@ RT_FN void light_ray(const DevScene<R>& sc, V3<R> point, V3<R>& ldir, R& limit) 
   limit = distance + eps<R>();
 }
 
+// Where the child rays of a wave's hits go: generation gen + 1 starts at child_start, this wave's children at
+// child_start + base (k_scan's prefix), reflected before refracted inside the wave.
+struct SpawnAt {
+  FrameCtl* ctl;
+  uint32_t child_start, base;
+};
+
+// The reflected ray of a hit (src/world.rs:68-76, src/intersection.rs:85) into its slot of the next generation, and
+// the hit's child record as far as it is known here.  Called by every lane of the wave; slot_r / slot_t mark the
+// lanes whose hit is on a reflective / transparent shape.  A transparent hit's refracted ray, its n1 / n2 and its
+// Schlick weight are k_spawn's part (ONLY_TRANSPARENT): it fills the other half of the child record.
+template <class R>
+RT_FN void spawn_reflection(const RayPool<R>& pool, uint32_t r, bool slot_r, bool slot_t, const Prepared<R>& c, const SpawnAt& at) {
+  const unsigned long long m_r = __builtin_amdgcn_ballot_w64(slot_r);
+  const uint32_t off_r = __popcll(m_r & lanes_below());
+  int32_t child_r = -1;
+  if (slot_r) {
+    const unsigned long long id = (unsigned long long)at.child_start + at.base + off_r;
+    if (id < (unsigned long long)pool.capacity) {
+      child_r = (int32_t)id;
+      st3(pool.org + 3ull * id, c.over_point);
+      st3(pool.dir + 3ull * id, reflect(c.d, c.normalv_temp));  // un-flipped normal (src/intersection.rs:85)
+    } else {
+      at.ctl->overflow.v = 1;
+    }
+  }
+  if (slot_r || slot_t) {
+    pool.child[2ull * r] = child_r;
+    if (!slot_t) pool.child[2ull * r + 1] = -1, pool.mixr[r] = R(-1);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // shade_surface: is_shadowed (src/world.rs:45-57) of the hit of ray r, then Material::lighting
 // (src/material.rs:108-162) with that flag; the surface colour goes to pool.color[r].  Called by all 64
 // lanes (the packet traversal needs them); `valid` marks the lanes whose ray hit prim p.
+// SPAWN: the reflected rays of the hits are written on the way (spawn_reflection), from the same prepared hit.
 // ------------------------------------------------------------------------------------------------
-template <class R, bool COUNT, bool PACKET>
-RT_FN void shade_surface(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t r, bool valid, int p, int flags, const HitRay<R>& h, int* lds, Work& wk) {
+template <class R, bool COUNT, bool PACKET, bool SPAWN>
+RT_FN void shade_surface(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t r, bool valid, int p, int flags, const HitRay<R>& h, int* lds, Work& wk, const SpawnAt* at) {
   Prepared<R> pc;
   pc.over_point = {R(0), R(0), R(0)};
   if (valid) pc = prepare(sc, h, p, flags);
+  if constexpr (SPAWN) spawn_reflection(pool, r, valid && (flags & PF_REFLECTIVE), valid && (flags & PF_TRANSPARENT), pc, *at);
   V3<R> ldir;
   R limit;
   light_ray(sc, pc.over_point, ldir, limit);
@@ -1549,7 +1584,10 @@ RT_FN void container_indices(const DevScene<R>& sc, bool need, int p, PrimInfo i
 // chain of the later generations.
 // One thread per ray; lanes whose ray missed idle.
 // ------------------------------------------------------------------------------------------------
-template <class R, bool COUNT, bool PACKET>
+// SPAWN: the launch also writes the reflected rays of the generation's hits (generation gen + 1): hit record, ray and
+// prepared hit are read and made once for both.  Chains that overlap with others run this way; k_spawn is then left
+// with the transparent hits alone.
+template <class R, bool COUNT, bool PACKET, bool SPAWN>
 __global__ void __launch_bounds__(BLOCK, PACKET ? RT355_WPS_PACKET : RT355_WPS_LANE) k_shadow(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int launch) {
   uint32_t start, gcount;
   gen_range(ctl, gen, pool.capacity, start, gcount);
@@ -1571,7 +1609,9 @@ __global__ void __launch_bounds__(BLOCK, PACKET ? RT355_WPS_PACKET : RT355_WPS_L
     if (__ballot(valid) == 0ull) continue;  // wave-uniform
     HitRay<R> h{};
     if (valid) h = load_hit_ray(pool, r, hit.flags);
-    shade_surface<R, COUNT, PACKET>(sc, pool, r, valid, valid ? hit.prim : 0, hit.flags, h, lds, wk);
+    SpawnAt at{ctl, start + gcount, 0u};
+    if constexpr (SPAWN) at.base = child_base(pool.blk_base, pool.blk_top, __builtin_amdgcn_readfirstlane(i) / GROUP);
+    shade_surface<R, COUNT, PACKET, SPAWN>(sc, pool, r, valid, valid ? hit.prim : 0, hit.flags, h, lds, wk, &at);
   }
   flush_work<COUNT>(ctl, launch, wk);
 }
@@ -1647,7 +1687,9 @@ __global__ void __launch_bounds__(BLOCK, 4) k_shadow_q(DevScene<R> sc, RayPool<R
 // ------------------------------------------------------------------------------------------------
 // The 64 rays of one wave: the child rays of their hits are placed from `base` (an offset into generation gen + 1,
 // this wave's own prefix) on, reflected before refracted.  Called by every lane of the wave.
-template <class R, bool COUNT, bool PACKET>
+// ONLY_T: the reflected rays were written by k_shadow<..., SPAWN>; what is left are the hits on transparent shapes --
+// n1 / n2, the refracted ray, the Schlick weight -- and waves without such a hit leave at once.
+template <class R, bool COUNT, bool PACKET, bool ONLY_T>
 RT_FN void spawn_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* ctl, int gen, uint32_t start, uint32_t gcount, uint32_t i, HitRec hit,
                        int any_transparent, int* lds, Work& wk) {
   const uint32_t child_start = start + gcount;
@@ -1656,13 +1698,13 @@ RT_FN void spawn_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* 
   // hits on shapes that neither reflect nor transmit have nothing to do here
   const bool slot_r = valid && (hit.flags & PF_REFLECTIVE);
   const bool slot_t = valid && (hit.flags & PF_TRANSPARENT);
-  if (__builtin_amdgcn_ballot_w64(slot_r | slot_t) == 0ull) return;  // wave-uniform
+  if (__builtin_amdgcn_ballot_w64(ONLY_T ? slot_t : (slot_r | slot_t)) == 0ull) return;  // wave-uniform
   const uint32_t base = child_base(pool.blk_base, pool.blk_top, __builtin_amdgcn_readfirstlane(i) / GROUP);
   const int p = valid ? hit.prim : 0;
   PrimInfo info;
   info.flags = hit.flags, info.shape = 0;
   HitRay<R> h{};
-  if (slot_r || slot_t) h = load_hit_ray(pool, r, hit.flags);
+  if (ONLY_T ? slot_t : (slot_r || slot_t)) h = load_hit_ray(pool, r, hit.flags);
   R n1 = R(1), n2 = R(1);
   if (any_transparent && __ballot(slot_t) != 0ull) {  // wave-uniform
     if (slot_t) info.shape = sc.prim_info[p].shape;
@@ -1671,7 +1713,7 @@ RT_FN void spawn_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* 
   bool want_refr = false;
   V3<R> refl_o = {R(0), R(0), R(0)}, refl_d = refl_o, refr_o = refl_o, refr_d = refl_o;
   R rs = R(-1);
-  if (slot_r || slot_t) {
+  if (ONLY_T ? slot_t : (slot_r || slot_t)) {
     const Prepared<R> c = prepare(sc, h, p, hit.flags);
     refl_o = c.over_point;
     refl_d = reflect(c.d, c.normalv_temp);  // un-flipped normal (src/intersection.rs:85)
@@ -1716,7 +1758,7 @@ RT_FN void spawn_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* 
   if ((threadIdx.x & 63u) == 0 && n_holes) atomicAdd(&ctl->holes[gen + 1].v, n_holes);
 
   int32_t child_r = -1, child_t = -1;
-  if (slot_r) {
+  if (!ONLY_T && slot_r) {
     const unsigned long long id = (unsigned long long)child_start + base + off_r;
     if (id < (unsigned long long)pool.capacity) {
       child_r = (int32_t)id;
@@ -1736,14 +1778,16 @@ RT_FN void spawn_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* 
       ctl->overflow.v = 1;
     }
   }
-  if (slot_r || slot_t) {  // k_combine looks at these only for hits on reflective / transparent shapes
+  if constexpr (ONLY_T) {
+    if (slot_t) pool.child[2ull * r + 1] = child_t, pool.mixr[r] = rs;
+  } else if (slot_r || slot_t) {  // k_combine looks at these only for hits on reflective / transparent shapes
     pool.child[2ull * r] = child_r;
     pool.child[2ull * r + 1] = child_t;
     pool.mixr[r] = rs;
   }
 }
 
-template <class R, bool COUNT, bool PACKET>
+template <class R, bool COUNT, bool PACKET, bool ONLY_T>
 __global__ void __launch_bounds__(BLOCK, PACKET ? RT355_WPS_SPAWN_PACKET : RT355_WPS_SPAWN) k_spawn(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int any_transparent, int launch) {
   __shared__ int lds_stack[PACKET ? 1 : LDS_STACK * BLOCK];
   int* lds = lds_stack + (PACKET ? 0 : threadIdx.x);
@@ -1759,7 +1803,7 @@ __global__ void __launch_bounds__(BLOCK, PACKET ? RT355_WPS_SPAWN_PACKET : RT355
     const uint32_t i = rbase + threadIdx.x;
     const HitRec hit = next;
     if (rbase + stride < gcount) next = load_hit(pool, start + (i + stride < gcount ? i + stride : 0u));
-    spawn_chunk<R, COUNT, PACKET>(sc, pool, ctl, gen, start, gcount, i, hit, any_transparent, lds, wk);
+    spawn_chunk<R, COUNT, PACKET, ONLY_T>(sc, pool, ctl, gen, start, gcount, i, hit, any_transparent, lds, wk);
   }
   flush_work<COUNT>(ctl, launch, wk);
 }

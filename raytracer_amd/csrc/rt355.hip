@@ -96,6 +96,7 @@ struct LaunchLog {
   int depth = 0;  // deepest generation
   bool shaded_in_trace = true;  // its trace launch also shades (k_trace<..., LAST>); false: a shadow launch of its own
   int kind[RT355_MAX_LAUNCH], gen[RT355_MAX_LAUNCH];
+  bool merged[RT355_MAX_GEN + 1] = {};  // the generation's shadow launch also wrote its reflected rays (k_shadow<..., SPAWN>)
 };
 
 struct rt355_ctx {
@@ -116,6 +117,9 @@ struct rt355_ctx {
   bool throughput_chain = false;  // the chain being queued was begun without waiting, or carries several frames
   int combine_levels = 2;  // generations folded into the first combine launch by walking ray subtrees (0..3)
   int shadow_lag = 0;   // the shadow launch of generation g is released behind the spawn of generation g + lag
+  int merge_spawn = -1;  // the shadow launch of a generation also writes its reflected rays, k_spawn only the refracted ones: 1 always, 0 never,
+                         // -1 for chains that overlap with others (one read of every hit for both, fewer launches; a frame rendered alone
+                         // keeps the shadow rays off its critical path instead)
   int use_side = 1;     // shadow launches on the side stream (0: everything on the main stream, e.g. with several frames in flight)
   int quad = 0;         // generations beyond packet_gens, four lanes to a ray instead of one: bit 0 k_trace_q, bit 1 k_shadow_q
   uint32_t grid0_cap = 0;  // blocks of a generation-0 launch at most (set to 32 per CU at creation; 0: one block per 256 rays).  A capped grid
@@ -329,7 +333,8 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, FrameC
   };
   // Shadow rays feed nothing but k_combine, so they leave the critical path: with per-launch timing or
   // counting off they run on the side stream.
-  const bool overlap = !c->timing && !COUNT && c->use_side;
+  const bool merge_all = c->merge_spawn >= 0 ? c->merge_spawn != 0 : c->throughput_chain;
+  const bool overlap = !c->timing && !COUNT && c->use_side && !merge_all;
   for (int g = 0; g <= depth; ++g) {
     // generation g > 0 can hold at most twice the hits of g-1; its size is only known on the device
     const uint32_t grid = g == 0 ? grid0 : std::min<uint32_t>(grid_cap, (uint32_t)((pool.capacity + BLOCK - 1) / BLOCK));
@@ -358,13 +363,32 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, FrameC
     hipLaunchKernelGGL(k_scan, dim3(std::min<uint32_t>(64u, scan_blocks(std::min<uint64_t>((uint64_t)pool.capacity, (uint64_t)n_primary << g)))), dim3(1024), 0, c->stream, pool.blk_hits, pool.blk_children, pool.blk_base,
                        pool.blk_top, ctl, g, (long long)pool.capacity);
     log.n++;
-    if (g < depth) {  // the deepest generation spawns nothing
+    // merged plan: one launch shades the generation's hits and writes their reflected rays; k_spawn follows for the
+    // transparent hits only, when the scene has any
+    const bool merged = merge_all && !last && !(!packet && (c->quad & 2));
+    log.merged[g] = merged;
+    if (merged) {
+      if ((rc = rec(RT355_K_SHADE, g))) return rc;
+      if (packet)
+        hipLaunchKernelGGL((k_shadow<R, COUNT, true, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, log.n);
+      else
+        hipLaunchKernelGGL((k_shadow<R, COUNT, false, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, log.n);
+      log.n++;
+      if (any_t) {
+        if ((rc = rec(RT355_K_SPAWN, g))) return rc;
+        if (packet)
+          hipLaunchKernelGGL((k_spawn<R, COUNT, true, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, any_t, log.n);
+        else
+          hipLaunchKernelGGL((k_spawn<R, COUNT, false, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, any_t, log.n);
+        log.n++;
+      }
+    } else if (g < depth) {  // the deepest generation spawns nothing
       if ((rc = rec(RT355_K_SPAWN, g))) return rc;
       const int launch_id = log.n;
       if (packet)
-        hipExtLaunchKernelGGL((k_spawn<R, COUNT, true>), dim3(grid), dim3(block), 0, c->stream, nullptr, done, 0, sc, pool, ctl, g, any_t, launch_id);
+        hipExtLaunchKernelGGL((k_spawn<R, COUNT, true, false>), dim3(grid), dim3(block), 0, c->stream, nullptr, done, 0, sc, pool, ctl, g, any_t, launch_id);
       else
-        hipExtLaunchKernelGGL((k_spawn<R, COUNT, false>), dim3(grid), dim3(block), 0, c->stream, nullptr, done, 0, sc, pool, ctl, g, any_t, launch_id);
+        hipExtLaunchKernelGGL((k_spawn<R, COUNT, false, false>), dim3(grid), dim3(block), 0, c->stream, nullptr, done, 0, sc, pool, ctl, g, any_t, launch_id);
       log.n++;
     }
     // Shadow launches.  The one of generation g - lag is released here, behind the spawn of generation g:
@@ -375,17 +399,17 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, FrameC
       int rc2;
       if ((rc2 = rec(RT355_K_SHADE, sg))) return rc2;
       if (sg < packet_gens)
-        hipLaunchKernelGGL((k_shadow<R, COUNT, true>), dim3(sgrid), dim3(block), 0, st, sc, pool, ctl, sg, log.n);
+        hipLaunchKernelGGL((k_shadow<R, COUNT, true, false>), dim3(sgrid), dim3(block), 0, st, sc, pool, ctl, sg, log.n);
       else if (c->quad & 2)
         hipLaunchKernelGGL((k_shadow_q<R, COUNT>), dim3(sgrid), dim3(block), 0, st, sc, pool, ctl, sg, log.n);
       else
-        hipLaunchKernelGGL((k_shadow<R, COUNT, false>), dim3(sgrid), dim3(block), 0, st, sc, pool, ctl, sg, log.n);
+        hipLaunchKernelGGL((k_shadow<R, COUNT, false, false>), dim3(sgrid), dim3(block), 0, st, sc, pool, ctl, sg, log.n);
       log.n++;
       return (int)RT355_OK;
     };
     const bool shaded_in_trace = last && !quad;  // k_trace<..., LAST> shades its own hits
     if (!overlap) {
-      if (!shaded_in_trace && (rc = shadow(g, c->stream))) return rc;
+      if (!shaded_in_trace && !merged && (rc = shadow(g, c->stream))) return rc;
       continue;
     }
     const int lag = c->shadow_lag;
@@ -469,7 +493,8 @@ int finish_stats(rt355_ctx* c, const LaunchLog& log, double frame_ms, rt355_stat
       const int g = log.gen[i];
       if (log.kind[i] == RT355_K_SHADE || (log.kind[i] == RT355_K_TRACE && g == log.depth && log.shaded_in_trace))
         fl += F_SHADE * (double)hits_of[g];  // over_point + lighting of every hit
-      if (log.kind[i] == RT355_K_SPAWN)
+      // reflect / refract of the spawned rays: charged to the launch that writes the reflected ones
+      if ((log.kind[i] == RT355_K_SPAWN && !log.merged[g]) || (log.kind[i] == RT355_K_SHADE && log.merged[g]))
         fl += 0.5 * (F_REFLECT + F_REFRACT) * (double)h.gen_count[g + 1].v;
       if (log.kind[i] == RT355_K_COMBINE) fl += 8.0 * (double)hits_of[g];  // surface + refl * R + refr * (1 - R)
       st->launch_flops[i] = fl;
@@ -750,6 +775,7 @@ int rt355_ctx_create_ex(rt355_ctx** out, int device_id, int real_bits, int flags
   if (const char* e = getenv("RT355_COMBINE_LEVELS")) c->combine_levels = std::max(0, std::min(3, atoi(e)));
   if (const char* e = getenv("RT355_SHADOW_LAG")) c->shadow_lag = std::max(0, atoi(e));
   if (const char* e = getenv("RT355_QUAD")) c->quad = atoi(e) & 3;
+  if (const char* e = getenv("RT355_MERGE_SPAWN")) c->merge_spawn = atoi(e) != 0;
   if (const char* e = getenv("RT355_GRID0_CAP")) c->grid0_cap = (uint32_t)std::max(0, atoi(e));
   *out = c;
   return RT355_OK;

@@ -37,7 +37,7 @@ constexpr int GROUP = 64;            // rays per entry of the child-slot bookkee
 #define RT355_WPS_PACKET_LAST 3
 #endif
 #ifndef RT355_WPS_SPAWN_PACKET
-#define RT355_WPS_SPAWN_PACKET 3
+#define RT355_WPS_SPAWN_PACKET 4
 #endif
 constexpr uint32_t LEAF_FIRST_MASK = 0x1FFFFFFu;  // leaf reference ~c: first | tri-only flag << 25 | count << 26
 constexpr uint32_t LEAF_TRI_BIT = 1u << 25;       // every prim of the leaf is a triangle with identity transform

@@ -304,14 +304,16 @@ def test_render_is_deterministic(dev):
 
 @pytest.mark.parametrize("env", [{"RT355_QUAD": "3"}, {"RT355_QUAD": "1"}, {"RT355_PACKET_GENS": "0", "RT355_QUAD": "3"},
                                  {"RT355_PACKET_GENS": "0"}, {"RT355_PACKET_GENS": "6"},
-                                 {"RT355_COMBINE_LEVELS": "0"}, {"RT355_PACKET_GENS": "1"}],
+                                 {"RT355_COMBINE_LEVELS": "0"}, {"RT355_PACKET_GENS": "1"}, {"RT355_MERGE_SPAWN": "1"},
+                                 {"RT355_MERGE_SPAWN": "1", "RT355_PACKET_GENS": "0"}, {"RT355_MERGE_SPAWN": "1", "RT355_PACKET_GENS": "6"}],
                          ids=["quad", "quad-trace", "quad-all", "per-lane-all", "packet-all", "combine-per-generation",
-                              "packet-primary-only"])
+                              "packet-primary-only", "merged-spawn", "merged-spawn-per-lane", "merged-spawn-packets"])
 @pytest.mark.parametrize("real_bits", [64, 32])
 def test_every_launch_plan_renders_the_same_image(env, real_bits):
     """The frame can be run through other kernels than the default ones (chosen at context creation from the
     environment): the traversal with four lanes to a ray, wave packets or single lanes for every generation,
-    one combine launch per generation.  A ray's colour is a
+    one combine launch per generation, the reflected rays written by the shadow launch (the plan of chains that
+    overlap) or by k_spawn (the plan of a frame rendered alone).  A ray's colour is a
     function of the ray alone, so every plan must give the default plan's image (bit for bit in double), and the
     same hits and shadow flags in the probes."""
     import os
