@@ -79,6 +79,11 @@ struct DbgAcc {
   uint32_t trips = 0, n_node = 0, n_leaf = 0;
 };
 #endif
+// Every traversal function and kernel is compiled per MODE: whether it counts its work, and whether the scene holds
+// instanced meshes (prims of kind RT355_INSTANCE with a tree of their own below them).  Scenes without instances --
+// the common case -- run kernels that carry no trace of them.
+constexpr int M_COUNT = 1, M_INST = 2;
+
 struct Work {  // per-thread work counters (counting mode only)
   uint32_t box = 0, xf = 0, prim[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef RT355_EXP_STAMPS
@@ -111,8 +116,8 @@ RT_FN void dbg_record(int launch, unsigned long long t0, unsigned long long c0, 
 #endif
 // Counters of one thread -> FrameCtl.  Reduced over the wave first (every lane of the wave calls this at
 // the end of its kernel), so the per-launch totals cost 11 atomics per wave, not per lane.
-template <bool COUNT> RT_FN void flush_work(FrameCtl* ctl, int launch, const Work& w) {
-  if constexpr (COUNT) {
+template <bool COUNTING> RT_FN void flush_work(FrameCtl* ctl, int launch, const Work& w) {
+  if constexpr (COUNTING) {
     if (launch >= RT355_MAX_LAUNCH) return;
     auto wsum = [](uint32_t v) {
       unsigned long long t = v;
@@ -154,25 +159,30 @@ RT_FN T load_uniform(const T* p) {
 // emit(t, u, v, emission_index) is called once per intersection, in the reference's emission order.
 // ------------------------------------------------------------------------------------------------
 // UNIFORM: p is the same in every lane of the wave (the every-ray list, the leaves of a packet traversal).
-template <class R, bool COUNT, bool UNIFORM = false, class Emit>
+template <class R, int MODE, bool UNIFORM = false, class Emit>
 RT_FN void prim_hits(const DevScene<R>& sc, int p, int flags, V3<R> wo, V3<R> wd, Work& wk, Emit&& emit) {
   const int kind = flags & PF_KIND_MASK;
-  if constexpr (COUNT) wk.prim[kind]++;
+  if constexpr (MODE & M_COUNT) wk.prim[kind]++;
   V3<R> o = wo, d = wd;
   R ext_min = R(0), ext_max = R(0);
   // the w term of inverse * direction, m[k][3] * 0.0 (src/ray.rs:35): a signed zero, -0.0 where the inverse's
   // translation entry is negative.  It decides nothing but the sign of a zero direction component, which the cube's
   // slab test tells apart (below).  The identity's entries are +0.0.
   V3<R> w_term = {R(0), R(0), R(0)};
-  if (!(flags & PF_IDENTITY) || kind == RT355_CYLINDER || kind == RT355_CONE) {
+  const bool instanced = (MODE & M_INST) != 0 && (flags & PF_INSTANCED) != 0;  // scenes without instances never look at inst_of
+  if (!(flags & PF_IDENTITY) || instanced || kind == RT355_CYLINDER || kind == RT355_CONE) {
+    // a triangle of an instanced mesh is the identity inside its mesh's tree; seen from the world (this function is
+    // called with world-space rays: the hit shape's own intersections for n1 / n2) it carries its instance's transformation
+    int xp = p;
+    if constexpr ((MODE & M_INST) != 0) xp = instanced ? sc.inst_of[p] : p;
     DevXform<R> X;
-    if constexpr (UNIFORM) X = load_uniform(&sc.xform[p]); else X = sc.xform[p];
+    if constexpr (UNIFORM) X = load_uniform(&sc.xform[xp]); else X = sc.xform[xp];
     ext_min = X.ymin, ext_max = X.ymax;
-    if (!(flags & PF_IDENTITY)) {
+    if (!(flags & PF_IDENTITY) || instanced) {
       o = xf_point(X.r, wo);
       d = xf_vec(X.r, wd);
       w_term = {X.r[3] * R(0), X.r[7] * R(0), X.r[11] * R(0)};
-      if constexpr (COUNT) wk.xf++;
+      if constexpr (MODE & M_COUNT) wk.xf++;
     }
   }
   const R EPS = eps<R>();
@@ -378,15 +388,17 @@ RT_FN bool slab_test(const SlabRay& s, float lox, float loy, float loz, float hi
 // The stack lives in LDS, one column per lane (lds[k * BLOCK]), so a push / pop is a conflict-free
 // ds_write / ds_read instead of a scratch round trip; entries beyond LDS_STACK spill to scratch.
 // ------------------------------------------------------------------------------------------------
-template <class R, bool COUNT, class Vis>
-RT_FN void traverse(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work& wk, int* lds) {
-  for (int p = sc.n_bounded; p < sc.n_prims; ++p)
-    if (vis.prim_u(p)) return;
-  if (sc.n_nodes == 0) return;
+// walk(): one tree, from `root`, for the ray (o, d) the visitor holds; the stack entries [0, sp0) belong to an outer
+// walk and are left alone.  Returns true when the visitor asked to stop.
+// A leaf prim of kind RT355_INSTANCE (MODE & M_INST only) is an instanced mesh: the ray is taken to the mesh's object
+// space -- once, not once per triangle -- and the mesh's own tree is walked with it, by this same function one level
+// down.  The parameter t is the same on both sides (the direction is transformed, not normalised: src/ray.rs:32-37),
+// so the visitor's interval carries over; only its ray is exchanged for the inner walk and put back afterwards.
+template <class R, int MODE, class Vis>
+RT_FN bool walk(const DevScene<R>& sc, int root, V3<R> o, V3<R> d, Vis& vis, Work& wk, int* lds, int* spill, const int sp0) {
   const SlabRay sr = make_slab_ray(o, d, sc.box_abs_max);
-  int spill[STACK_DEPTH - LDS_STACK];
-  int sp = 0;
-  int cur = 0;
+  int sp = sp0;
+  int cur = root;
   for (;;) {
 #ifdef RT355_EXP_STAMPS
     DbgAcc& dacc = wk.dbg;
@@ -408,7 +420,7 @@ RT_FN void traverse(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work& wk,
       if (!slab_test(sr, N.box[2][0], N.box[2][2], N.box[2][4], N.box[2][1], N.box[2][3], N.box[2][5], tlo, thi, k2)) k2 = INFINITY;
       if (!slab_test(sr, N.box[3][0], N.box[3][2], N.box[3][4], N.box[3][1], N.box[3][3], N.box[3][5], tlo, thi, k3)) k3 = INFINITY;
       int c0 = N.c[0], c1 = N.c[1], c2 = N.c[2], c3 = N.c[3];
-      if constexpr (COUNT) wk.box += (c0 != -1) + (c1 != -1) + (c2 != -1) + (c3 != -1);
+      if constexpr (MODE & M_COUNT) wk.box += (c0 != -1) + (c1 != -1) + (c2 != -1) + (c3 != -1);
       // nearest first: 5-exchange sorting network on (entry, child)
       auto order = [](float& ka, int& ca, float& kb, int& cb) {
         const bool sw = kb < ka;
@@ -437,23 +449,46 @@ RT_FN void traverse(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work& wk,
 #pragma unroll
         for (int k = 0; k < LEAF_MAX; ++k)
           if (k < count) {
-            if constexpr (COUNT) wk.prim[T[k].flags & PF_KIND_MASK]++;
-            if (vis.tri(first + k, T[k])) return;
+            if constexpr (MODE & M_COUNT) wk.prim[T[k].flags & PF_KIND_MASK]++;
+            if (vis.tri(first + k, T[k])) return true;
           }
         for (int k = LEAF_MAX; k < count; ++k) {  // only leaves forced at the depth limit are larger
           const DevTri Tk = sc.tri[first + k];
-          if constexpr (COUNT) wk.prim[Tk.flags & PF_KIND_MASK]++;
-          if (vis.tri(first + k, Tk)) return;
+          if constexpr (MODE & M_COUNT) wk.prim[Tk.flags & PF_KIND_MASK]++;
+          if (vis.tri(first + k, Tk)) return true;
         }
       } else {
-        for (int k = 0; k < count; ++k)
-          if (vis.prim(first + k)) return;
+        for (int k = 0; k < count; ++k) {
+          const int p = first + k;
+          if constexpr ((MODE & M_INST) != 0) {
+            if ((sc.prim_info[p].flags & PF_KIND_MASK) == RT355_INSTANCE) {
+              const DevXform<R> X = sc.xform[p];
+              const V3<R> so = vis.o, sd = vis.d;
+              vis.o = xf_point(X.r, so), vis.d = xf_vec(X.r, sd);
+              if constexpr (MODE & M_COUNT) wk.xf++;
+              const bool stop = walk<R, MODE & ~M_INST>(sc, (int)X.root, vis.o, vis.d, vis, wk, lds, spill, sp);
+              vis.o = so, vis.d = sd;
+              if (stop) return true;
+              continue;
+            }
+          }
+          if (vis.prim(p)) return true;
+        }
       }
     }
-    if (sp == 0) return;
+    if (sp == sp0) return false;
     --sp;
     cur = sp < LDS_STACK ? lds[sp * BLOCK] : spill[sp - LDS_STACK];
   }
+}
+
+template <class R, int MODE, class Vis>
+RT_FN void traverse(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work& wk, int* lds) {
+  for (int p = sc.n_bounded; p < sc.n_top; ++p)
+    if (vis.prim_u(p)) return;
+  if (sc.n_bounded == 0) return;
+  int spill[STACK_DEPTH - LDS_STACK];
+  (void)walk<R, MODE>(sc, 0, o, d, vis, wk, lds, spill, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -508,11 +543,14 @@ RT_FN bool slab_test_p(const SlabRayP& s, f32x2 bx, f32x2 by, f32x2 bz, float tl
   return tn <= tf;
 }
 
-template <class R, bool COUNT, class Vis>
-RT_FN void traverse_packet(const DevScene<R>& sc, V3<R> o, V3<R> d, bool live, Vis& vis, Work& wk, int* /*unused*/) {
-  for (int p = sc.n_bounded; p < sc.n_prims; ++p)
-    if (live && vis.prim_u(p)) live = false;
-  if (sc.n_nodes == 0) return;
+// walk_packet(): one tree, from `root`, for the wave's rays (o, d); the stack slots [0, sp0) belong to an outer walk,
+// which passes its stack register BY VALUE: this walk pushes and pops above sp0 in its own copy and the caller's is
+// as it was (taken by reference, the register costs every packet kernel 24 more vector registers and a wave per SIMD).
+// Lanes whose visitor is done leave `live` (returned); the walk ends when the tree is exhausted or no lane is left.  An instanced
+// mesh in a leaf (MODE & M_INST) takes every ray of the wave to the mesh's object space with one transformation read
+// through the scalar cache, and the wave walks the mesh's tree, one level down, the same way.
+template <class R, int MODE, class Vis>
+RT_FN bool walk_packet(const DevScene<R>& sc, int root, V3<R> o, V3<R> d, bool live, Vis& vis, Work& wk, int stackv, const int sp0) {
   const SlabRayP sr = make_slab_ray_p(make_slab_ray(o, d, sc.box_abs_max));
   // every visitor's lower bound is fixed for the length of a traversal
   float tlo;
@@ -520,17 +558,12 @@ RT_FN void traverse_packet(const DevScene<R>& sc, V3<R> o, V3<R> d, bool live, V
     const float a = (float)vis.tmin();
     tlo = a - fabsf(a) * 1.1920929e-7f;
   }
-  // The stack is ONE vector register: slot k lives in lane k (STACK_DEPTH == 64 lanes), pushed with a compare and a
-  // select against the lane number and popped with v_readlane from a scalar stack pointer -- no LDS round trip
-  // between a leaf and the next node.
-  static_assert(STACK_DEPTH == 64, "the packet stack is one lane per slot");
   const int lane_id = (int)(threadIdx.x & 63u);
-  int stackv = 0;
-  int sp = 0;
-  int cur = 0;
+  int sp = sp0;
+  int cur = root;
   for (;;) {
     const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(live);
-    if (live_mask == 0ull) return;
+    if (live_mask == 0ull) return live;
 #ifdef RT355_EXP_STAMPS
     DbgAcc& dacc = wk.dbg;
     const unsigned long long dc0 = __builtin_amdgcn_s_memtime();
@@ -560,7 +593,7 @@ RT_FN void traverse_packet(const DevScene<R>& sc, V3<R> o, V3<R> d, bool live, V
         float tn;
         // the compare's own lane mask, narrowed to the live lanes on the scalar unit
         const unsigned long long m = __builtin_amdgcn_ballot_w64(slab_test_p(sr, B[k][0], B[k][1], B[k][2], tlo, thi, tn)) & live_mask;
-        if constexpr (COUNT) n_valid += ch[k] != -1;
+        if constexpr (MODE & M_COUNT) n_valid += ch[k] != -1;
         // entry parameter of the first lane that touches the child; with no such lane the scalar bit search yields -1,
         // the lane read is then any lane's and the key is discarded.  Negative entries (visitors whose interval starts
         // below zero) order as zero.
@@ -568,7 +601,7 @@ RT_FN void traverse_packet(const DevScene<R>& sc, V3<R> o, V3<R> d, bool live, V
         const int bits = __builtin_amdgcn_readlane((int)__float_as_uint(tn), lane);
         key[k] = m ? (uint32_t)(bits < 0 ? 0 : bits) : 0xFFFFFFFFu;
       }
-      if constexpr (COUNT) wk.box += live ? n_valid : 0;
+      if constexpr (MODE & M_COUNT) wk.box += live ? n_valid : 0;
       auto order = [](uint32_t& ka, int& ca, uint32_t& kb, int& cb) {
         if (kb < ka) {
           const uint32_t kt = ka; ka = kb, kb = kt;
@@ -606,23 +639,49 @@ RT_FN void traverse_packet(const DevScene<R>& sc, V3<R> o, V3<R> d, bool live, V
 #pragma unroll
           for (int k = 0; k < PACKET_LEAF_GROUP; ++k)
             if (h + k < count) {  // wave-uniform; lanes without a ray run along, the visitor ignores them
-              if constexpr (COUNT) wk.prim[T[k].flags & PF_KIND_MASK] += live ? 1 : 0;
+              if constexpr (MODE & M_COUNT) wk.prim[T[k].flags & PF_KIND_MASK] += live ? 1 : 0;
               live = live & !vis.tri_masked(first + h + k, T[k], live);
             }
         }
         for (int k = LEAF_MAX; k < count; ++k) {
           const DevTri Tk = load_tri_uniform(sc, first + k);
-          if constexpr (COUNT) wk.prim[Tk.flags & PF_KIND_MASK] += live ? 1 : 0;
+          if constexpr (MODE & M_COUNT) wk.prim[Tk.flags & PF_KIND_MASK] += live ? 1 : 0;
           live = live & !vis.tri_masked(first + k, Tk, live);
         }
       } else {
-        for (int k = 0; k < count; ++k)
-          if (live && vis.prim_u(first + k)) live = false;
+        for (int k = 0; k < count; ++k) {
+          const int p = first + k;
+          if constexpr ((MODE & M_INST) != 0) {
+            if ((load_uniform(&sc.prim_info[p]).flags & PF_KIND_MASK) == RT355_INSTANCE) {
+              const DevXform<R> X = load_uniform(&sc.xform[p]);
+              const V3<R> so = vis.o, sd = vis.d;
+              vis.o = xf_point(X.r, so), vis.d = xf_vec(X.r, sd);
+              if constexpr (MODE & M_COUNT) wk.xf += live ? 1 : 0;
+              live = walk_packet<R, MODE & ~M_INST>(sc, (int)X.root, vis.o, vis.d, live, vis, wk, stackv, sp);
+              vis.o = so, vis.d = sd;
+              continue;
+            }
+          }
+          if (live && vis.prim_u(p)) live = false;
+        }
       }
     }
-    if (sp == 0) return;
+    if (sp == sp0) return live;
     cur = __builtin_amdgcn_readlane(stackv, --sp);
   }
+}
+
+// The stack of a packet traversal is ONE vector register: slot k lives in lane k (STACK_DEPTH == 64 lanes), pushed with
+// a compare and a select against the lane number and popped with v_readlane from a scalar stack pointer -- no LDS
+// round trip between a leaf and the next node.
+template <class R, int MODE, class Vis>
+RT_FN void traverse_packet(const DevScene<R>& sc, V3<R> o, V3<R> d, bool live, Vis& vis, Work& wk, int* /*unused*/) {
+  static_assert(STACK_DEPTH == 64, "the packet stack is one lane per slot");
+  for (int p = sc.n_bounded; p < sc.n_top; ++p)
+    if (live && vis.prim_u(p)) live = false;
+  if (sc.n_bounded == 0) return;
+  int stackv = 0;
+  (void)walk_packet<R, MODE>(sc, 0, o, d, live, vis, wk, stackv, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -657,11 +716,11 @@ RT_FN bool quad_any(bool b) {
   return v != 0;
 }
 
-template <class R, bool COUNT, class Vis>
+template <class R, int MODE, class Vis>
 RT_FN void traverse_quad(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work& wk, int* stack) {
   const int ql = threadIdx.x & 3;
   bool stop = false;
-  for (int p = sc.n_bounded + ql; p < sc.n_prims; p += 4) stop |= vis.prim(p);
+  for (int p = sc.n_bounded + ql; p < sc.n_top; p += 4) stop |= vis.prim(p);
   if (quad_any(stop) || sc.n_nodes == 0) return;
   const SlabRay sr = make_slab_ray(o, d, sc.box_abs_max);
   float tlo, thi;
@@ -674,7 +733,7 @@ RT_FN void traverse_quad(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work
       const float* b = sc.nodes[cur].box[ql];
       const float lox = b[0], hix = b[1], loy = b[2], hiy = b[3], loz = b[4], hiz = b[5];
       const int child = sc.nodes[cur].c[ql];
-      if constexpr (COUNT) wk.box += child != -1;
+      if constexpr (MODE & M_COUNT) wk.box += child != -1;
       float tn;
       const bool h = slab_test(sr, lox, loy, loz, hix, hiy, hiz, tlo, thi, tn);
       // Nearest first.  Keys are made distinct by the lane number in their two lowest bits, misses sort
@@ -700,7 +759,7 @@ RT_FN void traverse_quad(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work
       if (leaf & LEAF_TRI_BIT) {
         for (int k = ql; k < count; k += 4) {
           const DevTri T = sc.tri[first + k];
-          if constexpr (COUNT) wk.prim[T.flags & PF_KIND_MASK]++;
+          if constexpr (MODE & M_COUNT) wk.prim[T.flags & PF_KIND_MASK]++;
           stop |= vis.tri(first + k, T);
         }
       } else {
@@ -718,7 +777,7 @@ RT_FN void traverse_quad(const DevScene<R>& sc, V3<R> o, V3<R> d, Vis& vis, Work
 
 // Nearest hit with t >= 0; among equal t the lowest shape index wins (stable sort src/world.rs:42 +
 // first minimum src/intersection.rs:151).  NaN t never qualifies.
-template <class R, bool COUNT>
+template <class R, int MODE>
 struct ClosestVis {
   const DevScene<R>& sc;
   V3<R> o, d;
@@ -740,13 +799,13 @@ struct ClosestVis {
   }
   RT_FN bool prim(int p) {
     const PrimInfo info = sc.prim_info[p];
-    prim_hits<R, COUNT>(sc, p, info.flags, o, d, wk, [&](R t, R u, R v, int) { accept(t, u, v, p, info.shape, info.flags); });
+    prim_hits<R, MODE>(sc, p, info.flags, o, d, wk, [&](R t, R u, R v, int) { accept(t, u, v, p, info.shape, info.flags); });
     return false;
   }
   // p is the same in every lane of the wave
   RT_FN bool prim_u(int p) {
     const PrimInfo info = load_uniform(&sc.prim_info[p]);
-    prim_hits<R, COUNT, true>(sc, p, info.flags, o, d, wk, [&](R t, R u, R v, int) { accept(t, u, v, p, info.shape, info.flags); });
+    prim_hits<R, MODE, true>(sc, p, info.flags, o, d, wk, [&](R t, R u, R v, int) { accept(t, u, v, p, info.shape, info.flags); });
     return false;
   }
   RT_FN bool tri(int p, const DevTri& T) {
@@ -784,7 +843,7 @@ struct ClosestVis {
 };
 
 // is_shadowed: some intersection with 0 <= t < limit (src/world.rs:45-57; limit = distance + EPSILON).
-template <class R, bool COUNT>
+template <class R, int MODE>
 struct AnyVis {
   const DevScene<R>& sc;
   V3<R> o, d;
@@ -796,14 +855,14 @@ struct AnyVis {
   RT_FN R tmax() const { return limit; }
   RT_FN bool prim(int p) {
     const PrimInfo info = sc.prim_info[p];
-    prim_hits<R, COUNT>(sc, p, info.flags, o, d, wk, [&](R t, R, R, int) {
+    prim_hits<R, MODE>(sc, p, info.flags, o, d, wk, [&](R t, R, R, int) {
       if (t >= R(0) && t < limit) found = true;
     });
     return found;
   }
   RT_FN bool prim_u(int p) {
     const PrimInfo info = load_uniform(&sc.prim_info[p]);
-    prim_hits<R, COUNT, true>(sc, p, info.flags, o, d, wk, [&](R t, R, R, int) {
+    prim_hits<R, MODE, true>(sc, p, info.flags, o, d, wk, [&](R t, R, R, int) {
       if (t >= R(0) && t < limit) found = true;
     });
     return found;
@@ -832,7 +891,7 @@ struct AnyVis {
 // the reversed ray, culled like any other, instead of a walk over the whole line.
 // The visitor works on the reversed ray (o, -d): its parameter is tr = -t (negating d negates every t
 // exactly), so "largest t below the bound" is "smallest tr above -bound".
-template <class R, bool COUNT>
+template <class R, int MODE>
 struct BackwardVis {
   const DevScene<R>& sc;
   V3<R> o, d;  // d is the REVERSED direction
@@ -859,13 +918,13 @@ struct BackwardVis {
   RT_FN bool prim(int p) {
     if (p == p_hit) return false;
     const PrimInfo info = sc.prim_info[p];
-    prim_hits<R, COUNT>(sc, p, info.flags, o, d, wk, [&](R tr, R, R, int) { accept(tr, p, info.shape, info.flags); });
+    prim_hits<R, MODE>(sc, p, info.flags, o, d, wk, [&](R tr, R, R, int) { accept(tr, p, info.shape, info.flags); });
     return false;
   }
   RT_FN bool prim_u(int p) {
     if (p == p_hit) return false;
     const PrimInfo info = load_uniform(&sc.prim_info[p]);
-    prim_hits<R, COUNT, true>(sc, p, info.flags, o, d, wk, [&](R tr, R, R, int) { accept(tr, p, info.shape, info.flags); });
+    prim_hits<R, MODE, true>(sc, p, info.flags, o, d, wk, [&](R tr, R, R, int) { accept(tr, p, info.shape, info.flags); });
     return false;
   }
   RT_FN bool tri(int p, const DevTri& T) {
@@ -994,7 +1053,7 @@ RT_FN void primary_ray(const DevCamera<R>& cam, uint32_t i, V3<R>& org, V3<R>& d
 // ------------------------------------------------------------------------------------------------
 template <class R> struct HitRay;
 struct SpawnAt;
-template <class R, bool COUNT, bool PACKET, bool SPAWN>
+template <class R, int MODE, bool PACKET, bool SPAWN>
 RT_FN void shade_surface(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t r, bool valid, int p, int flags, const HitRay<R>& h, int* lds, Work& wk, const SpawnAt* at);
 
 // One chunk of BLOCK rays of generation `gen`: World::intersect + hit() for the ray of every lane, records to
@@ -1003,7 +1062,7 @@ RT_FN void shade_surface(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t
 // except their own shading, so the chunk goes on to shade each hit (shadow ray + lighting) and leaves the
 // ray's final colour in pool.color: one launch, and one slowest-wave tail, instead of three.
 // wh / wc: this wave's hits and the upper bound of the child rays they spawn.
-template <class R, bool COUNT, bool PACKET, bool LAST>
+template <class R, int MODE, bool PACKET, bool LAST>
 RT_FN void trace_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* ctl, const DevCamera<R>& cam, int primary, uint32_t start, uint32_t count,
                        uint32_t base, int remaining, int launch, int* lds, Work& wk, uint32_t& wh, uint32_t& wc) {
   const uint32_t i = base + threadIdx.x;
@@ -1016,23 +1075,23 @@ RT_FN void trace_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* 
   } else {
     o = ray_origin(pool, r), d = ld3(pool.dir + 3ull * r);
   }
-  ClosestVis<R, COUNT> vis(sc, o, d, wk);
+  ClosestVis<R, MODE> vis(sc, o, d, wk);
   const bool live = valid && !(d.x == R(0) && d.y == R(0) && d.z == R(0));
   long long t_start = 0;
-  if constexpr (COUNT) t_start = clock64();
+  if constexpr (MODE & M_COUNT) t_start = clock64();
 #ifdef RT355_EXP_STAMPS
   const unsigned long long dbg_t0 = wall_clock64(), dbg_c0 = __builtin_amdgcn_s_memtime();
   wk.dbg = DbgAcc{};
 #endif
   if constexpr (PACKET) {
-    traverse_packet<R, COUNT>(sc, o, d, live, vis, wk, lds);
+    traverse_packet<R, MODE>(sc, o, d, live, vis, wk, lds);
   } else {
-    if (live) traverse<R, COUNT>(sc, o, d, vis, wk, lds);
+    if (live) traverse<R, MODE>(sc, o, d, vis, wk, lds);
   }
 #ifdef RT355_EXP_STAMPS
   dbg_record(launch, dbg_t0, dbg_c0, wk.dbg, live);
 #endif
-  if constexpr (COUNT) {
+  if constexpr (MODE & M_COUNT) {
     // longest traversal of one wave, in shader clocks (all lanes reconverge here)
     const unsigned long long dt = (unsigned long long)(clock64() - t_start);
     if ((threadIdx.x & 63u) == 0 && launch < RT355_MAX_LAUNCH) atomicMax(&ctl->work[launch][11], dt);
@@ -1053,7 +1112,7 @@ RT_FN void trace_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* 
   if constexpr (LAST) {
     if (__ballot(hit) != 0ull) {
       const HitRay<R> h{o, d, vis.best_t, vis.best_u, vis.best_v};
-      shade_surface<R, COUNT, PACKET, false>(sc, pool, r, hit, hit ? vis.best_p : 0, vis.best_flags, h, lds, wk, nullptr);
+      shade_surface<R, MODE, PACKET, false>(sc, pool, r, hit, hit ? vis.best_p : 0, vis.best_flags, h, lds, wk, nullptr);
     }
     if (valid && !hit) st3(pool.color + 3ull * r, V3<R>{R(0), R(0), R(0)});  // src/world.rs:61-63: a miss is black
   }
@@ -1063,7 +1122,7 @@ RT_FN void trace_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* 
 
 // k_trace: trace_chunk over generation `gen`, one chunk per block and trip.  Every wave leaves the hit count and the
 // child bound of its own 64 rays for k_scan (entry i / 64 of blk_hits / blk_children): no wave waits for another.
-template <class R, bool COUNT, bool PACKET, bool LAST>
+template <class R, int MODE, bool PACKET, bool LAST>
 __global__ void __launch_bounds__(BLOCK, PACKET ? (LAST ? RT355_WPS_PACKET_LAST : RT355_WPS_PACKET) : RT355_WPS_LANE) k_trace(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch, DevCamera<R> cam, int primary) {
   __shared__ int lds_stack[PACKET ? 1 : LDS_STACK * BLOCK];
   int* lds = lds_stack + (PACKET ? 0 : threadIdx.x);
@@ -1074,19 +1133,19 @@ __global__ void __launch_bounds__(BLOCK, PACKET ? (LAST ? RT355_WPS_PACKET_LAST 
   // ballots of the packet traversal
   for (uint32_t base = blockIdx.x * BLOCK; base < count; base += gridDim.x * BLOCK) {
     uint32_t wh, wc;
-    trace_chunk<R, COUNT, PACKET, LAST>(sc, pool, ctl, cam, primary, start, count, base, remaining, launch, lds, wk, wh, wc);
+    trace_chunk<R, MODE, PACKET, LAST>(sc, pool, ctl, cam, primary, start, count, base, remaining, launch, lds, wk, wh, wc);
     if ((threadIdx.x & 63u) == 0 && base + threadIdx.x < count) {
       const uint32_t e = (base + threadIdx.x) / GROUP;
       pool.blk_hits[e] = wh;
       pool.blk_children[e] = wc;
     }
   }
-  flush_work<COUNT>(ctl, launch, wk);
+  flush_work<(MODE & M_COUNT) != 0>(ctl, launch, wk);
 }
 
 // k_trace with the quad traversal: a wave takes 64 consecutive rays per trip, 16 at a time, four lanes to a ray.
 // Same outputs as k_trace (hit records, per-wave hit and child counts for k_scan).
-template <class R, bool COUNT>
+template <class R, int MODE>
 __global__ void __launch_bounds__(BLOCK, 4) k_trace_q(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch, DevCamera<R> cam, int primary) {
   __shared__ int lds_stack[QUADS * STACK_DEPTH];
   int* stack = lds_stack + (threadIdx.x >> 2);
@@ -1108,9 +1167,9 @@ __global__ void __launch_bounds__(BLOCK, 4) k_trace_q(DevScene<R> sc, RayPool<R>
       } else {
         o = ray_origin(pool, r), d = ld3(pool.dir + 3ull * r);
       }
-      ClosestVis<R, COUNT> vis(sc, o, d, wk);
+      ClosestVis<R, MODE> vis(sc, o, d, wk);
       const bool live = valid && !(d.x == R(0) && d.y == R(0) && d.z == R(0));  // the same in the four lanes of a quad
-      if (live) traverse_quad<R, COUNT>(sc, o, d, vis, wk, stack);
+      if (live) traverse_quad<R, MODE>(sc, o, d, vis, wk, stack);
       const bool mine = vis.quad_winner() && valid;  // one lane per ray
       const bool hit = mine && vis.best_p >= 0;
       if (mine) {
@@ -1135,12 +1194,12 @@ __global__ void __launch_bounds__(BLOCK, 4) k_trace_q(DevScene<R> sc, RayPool<R>
       pool.blk_children[e] = wc;
     }
   }
-  flush_work<COUNT>(ctl, launch, wk);
+  flush_work<(MODE & M_COUNT) != 0>(ctl, launch, wk);
 }
 
 // Frame control block back to zero, generation 0 sized: a launch instead of a host-to-device copy, which
 // from pageable memory would stall the host for longer than a small frame takes to render.
-__global__ void __launch_bounds__(256) k_reset_ctl(FrameCtl* ctl, uint32_t n_primary) {
+static __global__ void __launch_bounds__(256) k_reset_ctl(FrameCtl* ctl, uint32_t n_primary) {
   uint32_t* w = (uint32_t*)ctl;
   for (uint32_t i = threadIdx.x; i < sizeof(FrameCtl) / 4; i += blockDim.x) w[i] = 0;
   __syncthreads();
@@ -1182,7 +1241,7 @@ RT_FN uint32_t block_scan_1024(uint32_t v, uint32_t* s, uint32_t* total) {
   return before + inc;
 }
 
-__global__ void __launch_bounds__(1024) k_scan(const uint32_t* blk_hits, const uint32_t* blk_children, uint32_t* blk_base, uint32_t* blk_top, FrameCtl* ctl, int gen, long long capacity) {
+static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* blk_hits, const uint32_t* blk_children, uint32_t* blk_base, uint32_t* blk_top, FrameCtl* ctl, int gen, long long capacity) {
   __shared__ uint32_t s_scan[16];
   __shared__ uint32_t s_last;
   uint32_t start, count;
@@ -1458,7 +1517,7 @@ RT_FN void spawn_reflection(const RayPool<R>& pool, uint32_t r, bool slot_r, boo
 // lanes (the packet traversal needs them); `valid` marks the lanes whose ray hit prim p.
 // SPAWN: the reflected rays of the hits are written on the way (spawn_reflection), from the same prepared hit.
 // ------------------------------------------------------------------------------------------------
-template <class R, bool COUNT, bool PACKET, bool SPAWN>
+template <class R, int MODE, bool PACKET, bool SPAWN>
 RT_FN void shade_surface(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t r, bool valid, int p, int flags, const HitRay<R>& h, int* lds, Work& wk, const SpawnAt* at) {
   Prepared<R> pc;
   pc.over_point = {R(0), R(0), R(0)};
@@ -1467,12 +1526,12 @@ RT_FN void shade_surface(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t
   V3<R> ldir;
   R limit;
   light_ray(sc, pc.over_point, ldir, limit);
-  AnyVis<R, COUNT> av(sc, pc.over_point, ldir, limit, wk);
+  AnyVis<R, MODE> av(sc, pc.over_point, ldir, limit, wk);
 #ifndef RT355_EXP_NO_SHADOW_TRAV
   if constexpr (PACKET) {
-    traverse_packet<R, COUNT>(sc, pc.over_point, ldir, valid, av, wk, lds);
+    traverse_packet<R, MODE>(sc, pc.over_point, ldir, valid, av, wk, lds);
   } else {
-    if (valid) traverse<R, COUNT>(sc, pc.over_point, ldir, av, wk, lds);
+    if (valid) traverse<R, MODE>(sc, pc.over_point, ldir, av, wk, lds);
   }
 #endif
   if (valid) {
@@ -1494,14 +1553,14 @@ RT_FN void shade_surface(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t
 // Called by every lane of the wave (the packet traversal needs them all); `need` marks the lanes that
 // want an answer.
 // ------------------------------------------------------------------------------------------------
-template <class R, bool COUNT, bool PACKET>
+template <class R, int MODE, bool PACKET>
 RT_FN void container_indices(const DevScene<R>& sc, bool need, int p, PrimInfo info, V3<R> o, V3<R> d, R t_hit, int* lds, Work& wk, R& n1, R& n2) {
   const R t = need ? t_hit : R(1);
   // the hit shape's own intersections, emission order
   R h0 = R(0), h1 = R(0), h2 = R(0), h3 = R(0);
   int nh = 0;
   if (need)
-    prim_hits<R, COUNT>(sc, p, info.flags, o, d, wk, [&](R tt, R, R, int em) {
+    prim_hits<R, MODE>(sc, p, info.flags, o, d, wk, [&](R tt, R, R, int em) {
       if (em == 0) h0 = tt; else if (em == 1) h1 = tt; else if (em == 2) h2 = tt; else if (em == 3) h3 = tt;
       nh = em + 1;
     });
@@ -1546,11 +1605,11 @@ RT_FN void container_indices(const DevScene<R>& sc, bool need, int p, PrimInfo i
   int bound_s = info.shape;
   for (int step = 0; step < 4096; ++step) {
     if (PACKET ? (__ballot(searching) == 0ull) : !searching) break;
-    BackwardVis<R, COUNT> bv(sc, o, rd, p, bound_t, bound_s, floor_t, floor_s, wk);
+    BackwardVis<R, MODE> bv(sc, o, rd, p, bound_t, bound_s, floor_t, floor_s, wk);
     if constexpr (PACKET) {
-      traverse_packet<R, COUNT>(sc, o, rd, searching, bv, wk, lds);
+      traverse_packet<R, MODE>(sc, o, rd, searching, bv, wk, lds);
     } else {
-      if (searching) traverse<R, COUNT>(sc, o, rd, bv, wk, lds);
+      if (searching) traverse<R, MODE>(sc, o, rd, bv, wk, lds);
     }
     if (searching) {
       if (!bv.have) {
@@ -1558,7 +1617,7 @@ RT_FN void container_indices(const DevScene<R>& sc, bool need, int p, PrimInfo i
       } else {
         // is that shape present, i.e. does it have an odd number of intersections before the hit?
         int cnt = 0;
-        prim_hits<R, COUNT>(sc, bv.cp, bv.cflags, o, d, wk, [&](R tt, R, R, int) {
+        prim_hits<R, MODE>(sc, bv.cp, bv.cflags, o, d, wk, [&](R tt, R, R, int) {
           if (tt < t || (tt == t && bv.cs < info.shape)) ++cnt;
         });
         if (cnt & 1) {
@@ -1587,7 +1646,7 @@ RT_FN void container_indices(const DevScene<R>& sc, bool need, int p, PrimInfo i
 // SPAWN: the launch also writes the reflected rays of the generation's hits (generation gen + 1): hit record, ray and
 // prepared hit are read and made once for both.  Chains that overlap with others run this way; k_spawn is then left
 // with the transparent hits alone.
-template <class R, bool COUNT, bool PACKET, bool SPAWN>
+template <class R, int MODE, bool PACKET, bool SPAWN>
 __global__ void __launch_bounds__(BLOCK, PACKET ? RT355_WPS_PACKET : RT355_WPS_LANE) k_shadow(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int launch) {
   uint32_t start, gcount;
   gen_range(ctl, gen, pool.capacity, start, gcount);
@@ -1611,9 +1670,9 @@ __global__ void __launch_bounds__(BLOCK, PACKET ? RT355_WPS_PACKET : RT355_WPS_L
     if (valid) h = load_hit_ray(pool, r, hit.flags);
     SpawnAt at{ctl, start + gcount, 0u};
     if constexpr (SPAWN) at.base = child_base(pool.blk_base, pool.blk_top, __builtin_amdgcn_readfirstlane(i) / GROUP);
-    shade_surface<R, COUNT, PACKET, SPAWN>(sc, pool, r, valid, valid ? hit.prim : 0, hit.flags, h, lds, wk, &at);
+    shade_surface<R, MODE, PACKET, SPAWN>(sc, pool, r, valid, valid ? hit.prim : 0, hit.flags, h, lds, wk, &at);
   }
-  flush_work<COUNT>(ctl, launch, wk);
+  flush_work<(MODE & M_COUNT) != 0>(ctl, launch, wk);
 }
 
 // k_shadow with the quad traversal.  Per trip a wave takes 64 rays: (1) one lane per ray prepares the shadow
@@ -1621,7 +1680,7 @@ __global__ void __launch_bounds__(BLOCK, PACKET ? RT355_WPS_PACKET : RT355_WPS_L
 // 16 shadow rays at a time, four lanes to a ray; (3) one lane per ray again: lighting with the flag found.
 // Everything a wave exchanges through LDS is its own (no block barrier); LDS operations of one wave execute
 // in order, the fences only keep the compiler from moving them.
-template <class R, bool COUNT>
+template <class R, int MODE>
 __global__ void __launch_bounds__(BLOCK, 4) k_shadow_q(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int launch) {
   uint32_t start, gcount;
   gen_range(ctl, gen, pool.capacity, start, gcount);
@@ -1662,8 +1721,8 @@ __global__ void __launch_bounds__(BLOCK, 4) k_shadow_q(DevScene<R> sc, RayPool<R
         const uint32_t src = s_list[wbase + slot];
         const R* q = s_ray + (size_t)(wbase + src) * 7;
         const V3<R> so = ld3(q), sd = ld3(q + 3);
-        AnyVis<R, COUNT> av(sc, so, sd, q[6], wk);
-        traverse_quad<R, COUNT>(sc, so, sd, av, wk, stack);
+        AnyVis<R, MODE> av(sc, so, sd, q[6], wk);
+        traverse_quad<R, MODE>(sc, so, sd, av, wk, stack);
         const bool found = quad_any(av.found);
         if ((lane & 3u) == 0) s_found[wbase + src] = found ? 1 : 0;
       }
@@ -1676,7 +1735,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_shadow_q(DevScene<R> sc, RayPool<R
       st3(pool.color + 3ull * r, lighting(sc, mat, pc.over_point, pc.eyev, pc.normalv, s_found[threadIdx.x] != 0));
     }
   }
-  flush_work<COUNT>(ctl, launch, wk);
+  flush_work<(MODE & M_COUNT) != 0>(ctl, launch, wk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1689,7 +1748,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_shadow_q(DevScene<R> sc, RayPool<R
 // this wave's own prefix) on, reflected before refracted.  Called by every lane of the wave.
 // ONLY_T: the reflected rays were written by k_shadow<..., SPAWN>; what is left are the hits on transparent shapes --
 // n1 / n2, the refracted ray, the Schlick weight -- and waves without such a hit leave at once.
-template <class R, bool COUNT, bool PACKET, bool ONLY_T>
+template <class R, int MODE, bool PACKET, bool ONLY_T>
 RT_FN void spawn_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* ctl, int gen, uint32_t start, uint32_t gcount, uint32_t i, HitRec hit,
                        int any_transparent, int* lds, Work& wk) {
   const uint32_t child_start = start + gcount;
@@ -1708,7 +1767,7 @@ RT_FN void spawn_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* 
   R n1 = R(1), n2 = R(1);
   if (any_transparent && __ballot(slot_t) != 0ull) {  // wave-uniform
     if (slot_t) info.shape = sc.prim_info[p].shape;
-    container_indices<R, COUNT, PACKET>(sc, slot_t, p, info, h.o, h.d, h.t, lds, wk, n1, n2);
+    container_indices<R, MODE, PACKET>(sc, slot_t, p, info, h.o, h.d, h.t, lds, wk, n1, n2);
   }
   bool want_refr = false;
   V3<R> refl_o = {R(0), R(0), R(0)}, refl_d = refl_o, refr_o = refl_o, refr_d = refl_o;
@@ -1787,7 +1846,7 @@ RT_FN void spawn_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* 
   }
 }
 
-template <class R, bool COUNT, bool PACKET, bool ONLY_T>
+template <class R, int MODE, bool PACKET, bool ONLY_T>
 __global__ void __launch_bounds__(BLOCK, PACKET ? RT355_WPS_SPAWN_PACKET : RT355_WPS_SPAWN) k_spawn(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int any_transparent, int launch) {
   __shared__ int lds_stack[PACKET ? 1 : LDS_STACK * BLOCK];
   int* lds = lds_stack + (PACKET ? 0 : threadIdx.x);
@@ -1803,9 +1862,9 @@ __global__ void __launch_bounds__(BLOCK, PACKET ? RT355_WPS_SPAWN_PACKET : RT355
     const uint32_t i = rbase + threadIdx.x;
     const HitRec hit = next;
     if (rbase + stride < gcount) next = load_hit(pool, start + (i + stride < gcount ? i + stride : 0u));
-    spawn_chunk<R, COUNT, PACKET, ONLY_T>(sc, pool, ctl, gen, start, gcount, i, hit, any_transparent, lds, wk);
+    spawn_chunk<R, MODE, PACKET, ONLY_T>(sc, pool, ctl, gen, start, gcount, i, hit, any_transparent, lds, wk);
   }
-  flush_work<COUNT>(ctl, launch, wk);
+  flush_work<(MODE & M_COUNT) != 0>(ctl, launch, wk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1893,7 +1952,7 @@ __global__ void __launch_bounds__(256) k_untile(const T* gathered, T* out, int w
 }
 
 // World::is_shadowed for arbitrary points (parity probe)
-template <class R>
+template <class R, int MODE>
 __global__ void __launch_bounds__(BLOCK) k_shadow_points(DevScene<R> sc, const float* pts, uint32_t n, uint8_t* out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1903,8 +1962,8 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_points(DevScene<R> sc, const f
   V3<R> ldir;
   R limit;
   light_ray(sc, p, ldir, limit);
-  AnyVis<R, false> av(sc, p, ldir, limit, wk);
-  traverse<R, false>(sc, p, ldir, av, wk, lds_stack + threadIdx.x);
+  AnyVis<R, MODE> av(sc, p, ldir, limit, wk);
+  traverse<R, MODE>(sc, p, ldir, av, wk, lds_stack + threadIdx.x);
   out[i] = av.found ? 1 : 0;
 }
 
@@ -1919,8 +1978,8 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_points_q(DevScene<R> sc, const
   V3<R> ldir;
   R limit;
   light_ray(sc, p, ldir, limit);
-  AnyVis<R, false> av(sc, p, ldir, limit, wk);
-  traverse_quad<R, false>(sc, p, ldir, av, wk, lds_stack + (threadIdx.x >> 2));
+  AnyVis<R, 0> av(sc, p, ldir, limit, wk);
+  traverse_quad<R, 0>(sc, p, ldir, av, wk, lds_stack + (threadIdx.x >> 2));
   const bool found = quad_any(av.found);
   if ((threadIdx.x & 3u) == 0) out[i] = found ? 1 : 0;
 }
@@ -1950,7 +2009,7 @@ __global__ void __launch_bounds__(256) k_export_hits(DevScene<R> sc, RayPool<R> 
 }
 
 // Color::to_u8 (src/color.rs:97-111): round half away from zero, clamp, NaN -> 0.
-__global__ void __launch_bounds__(256) k_to_u8(const float* in, size_t n, uint8_t* out) {
+static __global__ void __launch_bounds__(256) k_to_u8(const float* in, size_t n, uint8_t* out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float v = roundf(in[i] * 255.0f);

@@ -4,37 +4,23 @@
 // kernel launches on that stream with no host round trip in between: generation sizes live in a
 // device-side control block that the kernels read (grid-stride loops over device-side counts), and the
 // block is read back once, after the frame, for the statistics.
-#include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
-
-#include <chrono>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
 #include <mutex>
-#include <string>
-#include <vector>
 
-#include "kernels.h"
+#include "frame.h"
 
 using namespace rt355;
 
+thread_local std::string rt355::g_err;
+
+// the launch chains are compiled one (type, mode) pair per translation unit: frame_inst.hip
+#define RT355_FRAME_EXTERN(R, MODE)                                                                                                       \
+  extern template int rt355::run_generations<R, MODE>(rt355_ctx*, const rt355_scene*, RayPool<R>&, FrameCtl*, uint32_t, int, const DevCamera<R>&, bool, \
+                                                      int, float*, LaunchLog&);
+RT355_FRAME_EXTERN(double, 0) RT355_FRAME_EXTERN(double, 1) RT355_FRAME_EXTERN(double, 2) RT355_FRAME_EXTERN(double, 3)
+RT355_FRAME_EXTERN(float, 0) RT355_FRAME_EXTERN(float, 1) RT355_FRAME_EXTERN(float, 2) RT355_FRAME_EXTERN(float, 3)
+#undef RT355_FRAME_EXTERN
+
 namespace {
-
-thread_local std::string g_err;
-
-int set_err(int code, const std::string& msg) {
-  g_err = msg;
-  return code;
-}
-
-#define HIP_TRY(expr)                                                                              \
-  do {                                                                                             \
-    hipError_t e_ = (expr);                                                                        \
-    if (e_ != hipSuccess)                                                                          \
-      return set_err(RT355_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));               \
-  } while (0)
 
 // FLOP weights per unit of work: 1 per add/sub/mul/div/sqrt/min/max/compare, FMA = 2.
 const double F_PRIMARY = 40, F_BOX = 24, F_XFORM = 33;
@@ -66,107 +52,9 @@ int scratch_address(int device, void** out) {
   return RT355_OK;
 }
 
-struct DevBuf {
-  void* p = nullptr;
-  size_t bytes = 0;
-  int ensure(size_t need) {
-    if (need <= bytes) return RT355_OK;
-    if (p) (void)hipFree(p);
-    p = nullptr, bytes = 0;
-    size_t want = need + need / 8;
-    if (hipMalloc(&p, want) != hipSuccess) {
-      p = nullptr;
-      return set_err(RT355_ENOMEM, "hipMalloc of " + std::to_string(want) + " bytes failed");
-    }
-    bytes = want;
-    return RT355_OK;
-  }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr, bytes = 0;
-  }
-};
-
 }  // namespace
 
-constexpr int64_t PACKET_SECONDARY_PRIMS = 64;  // scenes with at most this many reflective / transparent prims trace every generation in packets
-
-struct LaunchLog {
-  int n = 0;
-  int depth = 0;  // deepest generation
-  bool shaded_in_trace = true;  // its trace launch also shades (k_trace<..., LAST>); false: a shadow launch of its own
-  int kind[RT355_MAX_LAUNCH], gen[RT355_MAX_LAUNCH];
-  bool merged[RT355_MAX_GEN + 1] = {};  // the generation's shadow launch also wrote its reflected rays (k_shadow<..., SPAWN>)
-};
-
-struct rt355_ctx {
-  int device = 0;
-  int real_bits = 64;
-  hipStream_t stream = nullptr;
-  hipStream_t side = nullptr;  // shadow launches, beside the trace / spawn chain
-  hipEvent_t ev_traced[RT355_MAX_GEN] = {}, ev_side_done = nullptr;
-  double pool_factor = 8.0;
-  int counting = 0;  // 0 off, 1 the frame's own kernels instrumented, 2 per ray (every generation one ray per lane)
-  bool timing = false;
-  int exact_cones = 0;
-  // Generations 0..packet_gens-1 use the wave-packet traversal, the later ones one lane per ray.  -1: chosen per scene --
-  // every generation when few prims can spawn secondary rays (their reflections and refractions leave a handful of
-  // surfaces and stay coherent: 5 to 7 % more frames per second on the teapot and glass scenes), generation 0 only
-  // otherwise (100 000 small reflective shapes scatter the rays: packets are 11 to 42 % slower there).
-  int packet_gens = -1;
-  bool throughput_chain = false;  // the chain being queued was begun without waiting, or carries several frames
-  int combine_levels = 2;  // generations folded into the first combine launch by walking ray subtrees (0..3)
-  int shadow_lag = 0;   // the shadow launch of generation g is released behind the spawn of generation g + lag
-  int merge_spawn = -1;  // the shadow launch of a generation also writes its reflected rays, k_spawn only the refracted ones: 1 always, 0 never,
-                         // -1 for chains that overlap with others (one read of every hit for both, fewer launches; a frame rendered alone
-                         // keeps the shadow rays off its critical path instead)
-  int use_side = 1;     // shadow launches on the side stream (0: everything on the main stream, e.g. with several frames in flight)
-  int quad = 0;         // generations beyond packet_gens, four lanes to a ray instead of one: bit 0 k_trace_q, bit 1 k_shadow_q
-  uint32_t grid0_cap = 0;  // blocks of a generation-0 launch at most (set to 32 per CU at creation; 0: one block per 256 rays).  A capped grid
-                           // walks its rays in several trips, which spreads each wave's start-up (some 150 instructions) over more rays
-  DevBuf org, dir, hit_t, hit_uv, hit_prim, color, mixr, child, blk_hits, blk_children, blk_base, blk_top, ctl, io_in, io_out, io_out2;
-  hipEvent_t ev[RT355_MAX_LAUNCH + 1] = {};  // timing mode: one before every launch, one behind the last
-  FrameCtl* ctl_host = nullptr;  // pinned
-  void* views_dev = nullptr;   // the views of a batch of frames (RT355_MAX_BATCH x DevView<double>), read by generation 0
-  void* views_host = nullptr;  // pinned staging of the same
-  void* fixed_scratch = nullptr;  // this device's copy of the fixed workspace (rt355_render_device_noalloc)
-  std::string fixed_scratch_error;  // why it is null, if it is
-  // a frame begun with rt355_render_tiles_begin and not yet ended: its launches are queued, nothing was waited for
-  bool pending = false;
-  LaunchLog pending_log;
-  std::chrono::steady_clock::time_point pending_t0;
-  double pending_primary_flops = 0;
-  int n_cu = 256;
-};
-
-struct rt355_scene {
-  int device = 0;  // the scene's tables live on this device; any context of the device may render it
-  int real_bits = 64;
-  DevBuf nodes, prim_info, xform, tri, trin, materials;
-  int32_t n_nodes = 0, n_bounded = 0, n_prims = 0, n_materials = 0, max_depth = 0;
-  bool any_secondary = false, any_transparent = false;
-  int64_t n_secondary_prims = 0;  // prims whose material is reflective or transparent
-  float light_pos[3], light_int[3];
-  float box_abs_max = 0.f;
-  size_t device_bytes = 0;
-};
-
 namespace {
-
-template <class R>
-DevScene<R> dev_scene(const rt355_scene* s) {
-  DevScene<R> d;
-  d.nodes = (const BvhNode4*)s->nodes.p;
-  d.prim_info = (const PrimInfo*)s->prim_info.p;
-  d.xform = (const DevXform<R>*)s->xform.p;
-  d.tri = (const DevTri*)s->tri.p;
-  d.trin = (const DevTriNormals<R>*)s->trin.p;
-  d.materials = (const DevMaterial<R>*)s->materials.p;
-  d.n_nodes = s->n_nodes, d.n_bounded = s->n_bounded, d.n_prims = s->n_prims, d.n_materials = s->n_materials;
-  d.box_abs_max = s->box_abs_max;
-  for (int k = 0; k < 3; ++k) d.light_pos[k] = R(s->light_pos[k]), d.light_int[k] = R(s->light_int[k]);
-  return d;
-}
 
 // hsize / vsize as the integers the reference keeps them in (usize, src/camera.rs:12-13).  Checked before
 // any cast or allocation: NaN, infinities, sizes below 1 or beyond what a canvas can be are rejected.
@@ -246,9 +134,6 @@ int64_t tiles_per_rank_of(int width, int height, int n_ranks) {
   return (tx * ty + n_ranks - 1) / n_ranks;
 }
 
-// blocks of a k_scan launch over a generation of at most `rays` rays
-uint32_t scan_blocks(uint64_t rays) { return std::max<uint32_t>(1u, (uint32_t)(((rays + GROUP - 1) / GROUP + SCAN_CHUNK - 1) / SCAN_CHUNK)); }
-
 template <class R>
 int ensure_pool(rt355_ctx* c, uint64_t n_primary, bool secondary, RayPool<R>& pool) {
   double factor = secondary ? std::max(1.0, c->pool_factor) : 1.0;
@@ -309,152 +194,18 @@ int carve_pool(rt355_ctx* c, void* base, size_t bytes, uint64_t n_primary, bool 
 }
 
 
-// The frame.  Generation 0 (ids 0..n_primary) is either made from the camera by the first trace launch
-// (`primary`) or already in the pool.  Leaves the combined
-// generation-0 colours in pool.color[0..n_primary).
-template <class R, bool COUNT>
-int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, FrameCtl* ctl, uint32_t n_primary, int max_depth, const DevCamera<R>& cam, bool primary,
-                    int out_mode, float* out_dev, LaunchLog& log) {
-  DevScene<R> sc = dev_scene<R>(s);
-  // Packets do more arithmetic per ray and stall less: best for the rate of chains that overlap (begun, not waited
-  // for) or carry several frames; one frame alone, whose every kernel ends on its slowest wave, is done soonest with
-  // packets for generations 0 and 1 only.
-  const int packet_gens = c->counting == 2 ? 0 : c->packet_gens >= 0 ? c->packet_gens : s->n_secondary_prims > PACKET_SECONDARY_PRIMS ? 1 : c->throughput_chain ? (int)RT355_MAX_GEN : 2;
-  hipLaunchKernelGGL(k_reset_ctl, dim3(1), dim3(256), 0, c->stream, ctl, n_primary);
-  const int depth = s->any_secondary ? max_depth : 0;  // no reflective / transparent material: one generation
-  const int block = BLOCK;
-  uint32_t grid0 = (n_primary + BLOCK - 1) / BLOCK;  // one block per 256 rays
-  if (c->grid0_cap) grid0 = std::min(grid0, c->grid0_cap);
-  const uint32_t grid_cap = (uint32_t)c->n_cu * 16 * (256 / BLOCK);
-  auto rec = [&](int kind, int gen) {
-    if (c->timing && log.n < RT355_MAX_LAUNCH) HIP_TRY(hipEventRecord(c->ev[log.n], c->stream));
-    if (log.n < RT355_MAX_LAUNCH) log.kind[log.n] = kind, log.gen[log.n] = gen;
-    return RT355_OK;
-  };
-  // Shadow rays feed nothing but k_combine, so they leave the critical path: with per-launch timing or
-  // counting off they run on the side stream.
-  const bool merge_all = c->merge_spawn >= 0 ? c->merge_spawn != 0 : c->throughput_chain;
-  const bool overlap = !c->timing && !COUNT && c->use_side && !merge_all;
-  for (int g = 0; g <= depth; ++g) {
-    // generation g > 0 can hold at most twice the hits of g-1; its size is only known on the device
-    const uint32_t grid = g == 0 ? grid0 : std::min<uint32_t>(grid_cap, (uint32_t)((pool.capacity + BLOCK - 1) / BLOCK));
-    int rc;
-    if ((rc = rec(RT355_K_TRACE, g))) return rc;
-    const bool packet = g < packet_gens;
-    const bool quad = !packet && (c->quad & 1);
-    const bool last = g == depth;
-    const int prim = (g == 0 && primary) ? 1 : 0, any_t = s->any_transparent ? 1 : 0;
-    // with the side stream in use, the event it waits for rides on the completion signal of the generation's
-    // last launch on the main stream: a separate event record would put a marker packet, and some
-    // microseconds, between that launch and the next trace
-    hipEvent_t done = (overlap && !last) ? c->ev_traced[g] : nullptr;
-    if (quad)  // the deepest generation is shaded by a k_shadow_q launch of its own, below
-      hipLaunchKernelGGL((k_trace_q<R, COUNT>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n, cam, prim);
-    else if (packet && last)
-      hipLaunchKernelGGL((k_trace<R, COUNT, true, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, 0, log.n, cam, prim);
-    else if (packet)
-      hipLaunchKernelGGL((k_trace<R, COUNT, true, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n, cam, prim);
-    else if (last)
-      hipLaunchKernelGGL((k_trace<R, COUNT, false, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, 0, log.n, cam, prim);
-    else
-      hipLaunchKernelGGL((k_trace<R, COUNT, false, false>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, depth - g, log.n, cam, prim);
-    log.n++;
-    if ((rc = rec(RT355_K_SCAN, g))) return rc;
-    hipLaunchKernelGGL(k_scan, dim3(std::min<uint32_t>(64u, scan_blocks(std::min<uint64_t>((uint64_t)pool.capacity, (uint64_t)n_primary << g)))), dim3(1024), 0, c->stream, pool.blk_hits, pool.blk_children, pool.blk_base,
-                       pool.blk_top, ctl, g, (long long)pool.capacity);
-    log.n++;
-    // merged plan: one launch shades the generation's hits and writes their reflected rays; k_spawn follows for the
-    // transparent hits only, when the scene has any
-    const bool merged = merge_all && !last && !(!packet && (c->quad & 2));
-    log.merged[g] = merged;
-    if (merged) {
-      if ((rc = rec(RT355_K_SHADE, g))) return rc;
-      if (packet)
-        hipLaunchKernelGGL((k_shadow<R, COUNT, true, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, log.n);
-      else
-        hipLaunchKernelGGL((k_shadow<R, COUNT, false, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, log.n);
-      log.n++;
-      if (any_t) {
-        if ((rc = rec(RT355_K_SPAWN, g))) return rc;
-        if (packet)
-          hipLaunchKernelGGL((k_spawn<R, COUNT, true, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, any_t, log.n);
-        else
-          hipLaunchKernelGGL((k_spawn<R, COUNT, false, true>), dim3(grid), dim3(block), 0, c->stream, sc, pool, ctl, g, any_t, log.n);
-        log.n++;
-      }
-    } else if (g < depth) {  // the deepest generation spawns nothing
-      if ((rc = rec(RT355_K_SPAWN, g))) return rc;
-      const int launch_id = log.n;
-      if (packet)
-        hipExtLaunchKernelGGL((k_spawn<R, COUNT, true, false>), dim3(grid), dim3(block), 0, c->stream, nullptr, done, 0, sc, pool, ctl, g, any_t, launch_id);
-      else
-        hipExtLaunchKernelGGL((k_spawn<R, COUNT, false, false>), dim3(grid), dim3(block), 0, c->stream, nullptr, done, 0, sc, pool, ctl, g, any_t, launch_id);
-      log.n++;
-    }
-    // Shadow launches.  The one of generation g - lag is released here, behind the spawn of generation g:
-    // the next trace then reaches the device first and the shadow waves fill the SIMDs its tail leaves
-    // idle, instead of taking the block slots the chain is waiting for.
-    auto shadow = [&](int sg, hipStream_t st) {
-      const uint32_t sgrid = sg == 0 ? grid0 : std::min<uint32_t>(grid_cap, (uint32_t)((pool.capacity + BLOCK - 1) / BLOCK));
-      int rc2;
-      if ((rc2 = rec(RT355_K_SHADE, sg))) return rc2;
-      if (sg < packet_gens)
-        hipLaunchKernelGGL((k_shadow<R, COUNT, true, false>), dim3(sgrid), dim3(block), 0, st, sc, pool, ctl, sg, log.n);
-      else if (c->quad & 2)
-        hipLaunchKernelGGL((k_shadow_q<R, COUNT>), dim3(sgrid), dim3(block), 0, st, sc, pool, ctl, sg, log.n);
-      else
-        hipLaunchKernelGGL((k_shadow<R, COUNT, false, false>), dim3(sgrid), dim3(block), 0, st, sc, pool, ctl, sg, log.n);
-      log.n++;
-      return (int)RT355_OK;
-    };
-    const bool shaded_in_trace = last && !quad;  // k_trace<..., LAST> shades its own hits
-    if (!overlap) {
-      if (!shaded_in_trace && !merged && (rc = shadow(g, c->stream))) return rc;
-      continue;
-    }
-    const int lag = c->shadow_lag;
-    if (!last) {
-      HIP_TRY(hipStreamWaitEvent(c->side, c->ev_traced[g], 0));
-      if (g - lag >= 0 && (rc = shadow(g - lag, c->side))) return rc;
-    } else {
-      // every generation still waiting: their traces finished long ago
-      for (int sg = std::max(0, g - lag); sg < g; ++sg)
-        if ((rc = shadow(sg, c->side))) return rc;
-      if (!shaded_in_trace && (rc = shadow(g, c->stream))) return rc;  // behind its own trace, on the same stream
-    }
+
+// run_generations with the kernels the context's counting mode and the scene's contents ask for
+template <class R>
+int run_generations_mode(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, FrameCtl* ctl, uint32_t n_primary, int max_depth, const DevCamera<R>& cam, bool primary,
+                         int out_mode, float* out_dev, LaunchLog& log) {
+  const bool inst = s->n_instances > 0;
+  if (c->counting) {
+    return inst ? run_generations<R, M_COUNT | M_INST>(c, s, pool, ctl, n_primary, max_depth, cam, primary, out_mode, out_dev, log)
+                : run_generations<R, M_COUNT>(c, s, pool, ctl, n_primary, max_depth, cam, primary, out_mode, out_dev, log);
   }
-  log.depth = depth;
-  log.shaded_in_trace = !(depth >= packet_gens && (c->quad & 1));
-  if (overlap && depth > 0) {
-    HIP_TRY(hipEventRecord(c->ev_side_done, c->side));
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_side_done, 0));
-  }
-  // The deepest generation's colours are final already; generation 0 still has to reach the canvas.
-  // The generations right above the deepest one hold few rays, so one launch folds several of them: each
-  // ray of generation `top` walks its own subtree (at most 2^levels - 1 hits below it) instead of one
-  // latency-bound launch per generation.
-  const int levels = std::max(0, std::min(c->combine_levels, depth - 1));
-  const int top = depth > 0 ? depth - 1 - levels : 0;
-  for (int g = top; g >= 0; --g) {
-    // no traversal here: 256-thread blocks
-    const uint32_t grid = std::max<uint32_t>(1u, (g == 0 ? grid0 : std::min<uint32_t>(grid_cap, (uint32_t)((pool.capacity + BLOCK - 1) / BLOCK))) / (256 / BLOCK));
-    int rc;
-    if ((rc = rec(RT355_K_COMBINE, g))) return rc;
-    const int has_children = g < depth ? 1 : 0;
-    switch (g == top ? levels : 0) {
-      case 3: hipLaunchKernelGGL((k_combine<R, 3>), dim3(grid), dim3(256), 0, c->stream, sc, pool, ctl, g, has_children, cam, out_mode, out_dev); break;
-      case 2: hipLaunchKernelGGL((k_combine<R, 2>), dim3(grid), dim3(256), 0, c->stream, sc, pool, ctl, g, has_children, cam, out_mode, out_dev); break;
-      case 1: hipLaunchKernelGGL((k_combine<R, 1>), dim3(grid), dim3(256), 0, c->stream, sc, pool, ctl, g, has_children, cam, out_mode, out_dev); break;
-      default: hipLaunchKernelGGL((k_combine<R, 0>), dim3(grid), dim3(256), 0, c->stream, sc, pool, ctl, g, has_children, cam, out_mode, out_dev); break;
-    }
-    log.n++;
-  }
-  if (c->timing && log.n <= RT355_MAX_LAUNCH) HIP_TRY(hipEventRecord(c->ev[log.n], c->stream));
-  // counters and the overflow flag travel to pinned host memory behind the last kernel: the caller's one
-  // stream synchronisation makes them readable
-  HIP_TRY(hipMemcpyAsync(c->ctl_host, ctl, sizeof(FrameCtl), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipGetLastError());
-  return RT355_OK;
+  return inst ? run_generations<R, M_INST>(c, s, pool, ctl, n_primary, max_depth, cam, primary, out_mode, out_dev, log)
+              : run_generations<R, 0>(c, s, pool, ctl, n_primary, max_depth, cam, primary, out_mode, out_dev, log);
 }
 
 // After the stream has been synchronised behind run_generations.
@@ -547,10 +298,7 @@ int render_impl(rt355_ctx* c, const rt355_scene* s, const rt355_camera_desc* cam
   c->throughput_chain = begin_only || n_frames > 1;
   auto t0 = std::chrono::steady_clock::now();
   LaunchLog log;
-  if (c->counting)
-    rc = run_generations<R, true>(c, s, pool, ctl, (uint32_t)n_primary, max_depth, dc, true, out_mode, out_dev, log);
-  else
-    rc = run_generations<R, false>(c, s, pool, ctl, (uint32_t)n_primary, max_depth, dc, true, out_mode, out_dev, log);
+  rc = run_generations_mode<R>(c, s, pool, ctl, (uint32_t)n_primary, max_depth, dc, true, out_mode, out_dev, log);
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
   c->pending = true, c->pending_log = log, c->pending_t0 = t0;
@@ -575,10 +323,12 @@ int rays_impl(rt355_ctx* c, const rt355_scene* s, const float* rays_host, size_t
   if (trace_only) {
     DevScene<R> sc = dev_scene<R>(s);
     hipLaunchKernelGGL(k_reset_ctl, dim3(1), dim3(256), 0, c->stream, (FrameCtl*)c->ctl.p, (uint32_t)n);
-    if (c->quad & 1)
-      hipLaunchKernelGGL((k_trace_q<R, false>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (FrameCtl*)c->ctl.p, 0, 0, 0, DevCamera<R>{}, 0);
+    if (s->n_instances > 0)
+      hipLaunchKernelGGL((k_trace<R, M_INST, false, false>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (FrameCtl*)c->ctl.p, 0, 0, 0, DevCamera<R>{}, 0);
+    else if (c->quad & 1)
+      hipLaunchKernelGGL((k_trace_q<R, 0>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (FrameCtl*)c->ctl.p, 0, 0, 0, DevCamera<R>{}, 0);
     else
-      hipLaunchKernelGGL((k_trace<R, false, false, false>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (FrameCtl*)c->ctl.p, 0, 0, 0, DevCamera<R>{}, 0);
+      hipLaunchKernelGGL((k_trace<R, 0, false, false>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (FrameCtl*)c->ctl.p, 0, 0, 0, DevCamera<R>{}, 0);
     if ((rc = c->io_out.ensure(n * sizeof(double)))) return rc;
     if ((rc = c->io_out2.ensure(n * sizeof(int32_t)))) return rc;
     hipLaunchKernelGGL((k_export_hits<R>), dim3(grid0), dim3(block), 0, c->stream, sc, pool, (uint32_t)n, (double*)c->io_out.p, (int32_t*)c->io_out2.p);
@@ -593,10 +343,7 @@ int rays_impl(rt355_ctx* c, const rt355_scene* s, const float* rays_host, size_t
   if ((rc = c->io_out.ensure(n * 3 * sizeof(float)))) return rc;
   DevCamera<R> dummy;
   memset(&dummy, 0, sizeof(dummy));
-  if (c->counting)
-    rc = run_generations<R, true>(c, s, pool, (FrameCtl*)c->ctl.p, (uint32_t)n, max_depth, dummy, false, (int)OUT_LINEAR, (float*)c->io_out.p, log);
-  else
-    rc = run_generations<R, false>(c, s, pool, (FrameCtl*)c->ctl.p, (uint32_t)n, max_depth, dummy, false, (int)OUT_LINEAR, (float*)c->io_out.p, log);
+  rc = run_generations_mode<R>(c, s, pool, (FrameCtl*)c->ctl.p, (uint32_t)n, max_depth, dummy, false, (int)OUT_LINEAR, (float*)c->io_out.p, log);
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(rgb_out, c->io_out.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -619,9 +366,9 @@ int upload_impl(rt355_ctx* c, const HostScene& hs, rt355_scene* s) {
     for (int k = 0; k < BVH_WIDTH; ++k) {
       for (int a = 0; a < 3; ++a) {
         nodes[i].box[k][2 * a] = down(hs.nodes[i].lo[k][a]), nodes[i].box[k][2 * a + 1] = up(hs.nodes[i].hi[k][a]);
-        if (i == 0)  // node 0 is the root: its boxes enclose every other
-          for (float v : {nodes[i].box[k][2 * a], nodes[i].box[k][2 * a + 1]})
-            if (std::isfinite(v)) s->box_abs_max = std::max(s->box_abs_max, std::fabs(v));
+        // the largest coordinate of any box (the top tree's in world space, the instanced meshes' in their own)
+        for (float v : {nodes[i].box[k][2 * a], nodes[i].box[k][2 * a + 1]})
+          if (std::isfinite(v)) s->box_abs_max = std::max(s->box_abs_max, std::fabs(v));
       }
       nodes[i].c[k] = hs.nodes[i].c[k];
       if (nodes[i].c[k] == -1) {  // empty slot: both x planes at +inf, which no ray interval with finite ends overlaps
@@ -644,7 +391,7 @@ int upload_impl(rt355_ctx* c, const HostScene& hs, rt355_scene* s) {
     if (hs.materials[p.material].reflective > 0.f && hs.materials[p.material].transparency > 0.f) info[i].flags |= PF_SCHLICK;
     if (info[i].flags & (PF_REFLECTIVE | PF_TRANSPARENT)) n_secondary++;
     for (int k = 0; k < 12; ++k) xf[i].r[k] = (R)p.inv[k];
-    xf[i].ymin = (R)p.ymin, xf[i].ymax = (R)p.ymax, xf[i].pad0 = xf[i].pad1 = 0;
+    xf[i].ymin = (R)p.ymin, xf[i].ymax = (R)p.ymax, xf[i].root = (R)(p.blas_root >= 0 ? p.blas_root : 0), xf[i].pad1 = 0;
     if ((p.flags & PF_KIND_MASK) >= RT355_TRIANGLE) any_tri = true;
   }
   size_t n_optical = 0;  // prims whose refractive index is not 1 (the default, src/material.rs:31-72)
@@ -684,7 +431,14 @@ int upload_impl(rt355_ctx* c, const HostScene& hs, rt355_scene* s) {
   if ((rc = put(s->tri, tri.data(), tri.size() * sizeof(DevTri)))) return rc;
   if ((rc = put(s->trin, trin.data(), trin.size() * sizeof(DevTriNormals<R>)))) return rc;
   if ((rc = put(s->materials, mats.data(), nm * sizeof(DevMaterial<R>)))) return rc;
-  s->n_nodes = (int32_t)nn, s->n_bounded = hs.n_bounded, s->n_prims = (int32_t)np, s->n_materials = (int32_t)nm;
+  if (hs.n_instances > 0) {
+    if (nn >= (1u << 24)) return set_err(RT355_EINVAL, "too many BVH nodes for a scene with instanced meshes");  // roots are kept as whole numbers in R
+    std::vector<int32_t> inst_of(np);
+    for (size_t i = 0; i < np; ++i) inst_of[i] = hs.prims[i].inst_prim;
+    if ((rc = put(s->inst_of, inst_of.data(), np * sizeof(int32_t)))) return rc;
+  }
+  s->n_nodes = (int32_t)nn, s->n_bounded = hs.n_bounded, s->n_top = hs.n_top, s->n_prims = (int32_t)np, s->n_materials = (int32_t)nm;
+  s->n_instances = hs.n_instances;
   s->max_depth = hs.max_depth, s->any_secondary = hs.any_secondary, s->any_transparent = hs.any_transparent;
   s->n_secondary_prims = n_secondary;
   return RT355_OK;
@@ -851,13 +605,13 @@ int rt355_scene_upload(rt355_ctx* c, const rt355_shape_desc* shapes, size_t n_sh
 void rt355_scene_destroy(rt355_scene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
-  for (DevBuf* b : {&s->nodes, &s->prim_info, &s->xform, &s->tri, &s->trin, &s->materials}) b->release();
+  for (DevBuf* b : {&s->nodes, &s->prim_info, &s->xform, &s->tri, &s->trin, &s->materials, &s->inst_of}) b->release();
   delete s;
 }
 
 int rt355_scene_info(const rt355_scene* s, uint64_t out[5]) {
   if (!s || !out) return set_err(RT355_EINVAL, "null argument");
-  out[0] = s->n_nodes, out[1] = s->n_bounded, out[2] = s->n_prims - s->n_bounded, out[3] = s->max_depth, out[4] = s->device_bytes;
+  out[0] = s->n_nodes, out[1] = s->n_bounded, out[2] = s->n_top - s->n_bounded, out[3] = s->max_depth, out[4] = s->device_bytes;
   return RT355_OK;
 }
 
@@ -1050,15 +804,21 @@ int rt355_is_shadowed(rt355_ctx* c, const rt355_scene* s, const float* points, s
   if ((rc = c->io_out.ensure(n))) return rc;
   HIP_TRY(hipMemcpyAsync(c->io_in.p, points, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
   const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK), grid_q = (unsigned)((n + QUADS - 1) / QUADS);
-  if (c->quad & 2) {  // the traversal the frame's shadow launches use
+  const bool inst = s->n_instances > 0;
+  auto launch_points = [&](auto real, auto mode) {
+    using R = decltype(real);
+    hipLaunchKernelGGL((k_shadow_points<R, decltype(mode)::value>), dim3(grid), dim3(BLOCK), 0, c->stream, dev_scene<R>(s), (const float*)c->io_in.p, (uint32_t)n, (uint8_t*)c->io_out.p);
+  };
+  if ((c->quad & 2) && !inst) {  // the traversal the frame's shadow launches use
     if (c->real_bits == 32)
       hipLaunchKernelGGL((k_shadow_points_q<float>), dim3(grid_q), dim3(BLOCK), 0, c->stream, dev_scene<float>(s), (const float*)c->io_in.p, (uint32_t)n, (uint8_t*)c->io_out.p);
     else
       hipLaunchKernelGGL((k_shadow_points_q<double>), dim3(grid_q), dim3(BLOCK), 0, c->stream, dev_scene<double>(s), (const float*)c->io_in.p, (uint32_t)n, (uint8_t*)c->io_out.p);
-  } else if (c->real_bits == 32)
-    hipLaunchKernelGGL((k_shadow_points<float>), dim3(grid), dim3(BLOCK), 0, c->stream, dev_scene<float>(s), (const float*)c->io_in.p, (uint32_t)n, (uint8_t*)c->io_out.p);
-  else
-    hipLaunchKernelGGL((k_shadow_points<double>), dim3(grid), dim3(BLOCK), 0, c->stream, dev_scene<double>(s), (const float*)c->io_in.p, (uint32_t)n, (uint8_t*)c->io_out.p);
+  } else if (c->real_bits == 32) {
+    if (inst) launch_points(float(), std::integral_constant<int, M_INST>()); else launch_points(float(), std::integral_constant<int, 0>());
+  } else {
+    if (inst) launch_points(double(), std::integral_constant<int, M_INST>()); else launch_points(double(), std::integral_constant<int, 0>());
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, c->io_out.p, n, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1100,7 +860,7 @@ int rt355_scene_check(const rt355_shape_desc* shapes, size_t n_shapes, int real_
   int rc = build_host_scene(shapes, n_shapes, pad_rel, exact_cones ? INT64_MAX : 32, hs, err, sizeof(err));
   if (rc) return set_err(rc, err);
   if ((rc = verify_host_scene(hs, err, sizeof(err)))) return set_err(rc, err);
-  out[0] = hs.nodes.size(), out[1] = (uint64_t)hs.n_bounded, out[2] = hs.prims.size() - (size_t)hs.n_bounded;
+  out[0] = hs.nodes.size(), out[1] = (uint64_t)hs.n_bounded, out[2] = (uint64_t)(hs.n_top - hs.n_bounded);
   out[3] = (uint64_t)hs.max_depth, out[4] = hs.materials.size();
   return RT355_OK;
 }

@@ -54,7 +54,14 @@ constexpr int PF_REFLECTIVE = 32;   // material.reflective != 0: a hit may spawn
 constexpr int PF_TRANSPARENT = 64;  // material.transparency != 0: a hit may spawn a refracted ray
 constexpr int PF_OTHERS_UNIT = 128;  // every OTHER prim of the scene has refractive index 1: n1 / n2 need less searching
 constexpr int PF_SCHLICK = 256;      // reflective > 0 && transparency > 0: the two child colours are mixed by schlick()
-constexpr int PF_MAT_SHIFT = 9;
+constexpr int PF_INSTANCED = 512;    // a triangle of an instanced mesh: identity inside its mesh's own tree, taken to world space by
+                                     // the transformation of its instance (inst_of[p] is the instance's prim)
+constexpr int PF_MAT_SHIFT = 10;
+// Device-side prim kind of an instanced mesh: a run of triangles of World.shapes that share one transformation (what
+// Scene::to_transformed_shapes leaves of a group with a mesh below it, src/group.rs:117-168) is kept in object space
+// under a tree of its own; the top tree holds one prim for it.  Groups themselves never reach the device
+// (src/shape.rs:376), so their kind number is free.
+constexpr int RT355_INSTANCE = RT355_GROUP;
 
 struct PrimInfo {
   int32_t shape;  // index in World.shapes
@@ -84,7 +91,8 @@ template <class R>
 struct DevXform {  // rows 0..2 of the inverse transformation (affine): x' = r0 . (x,y,z,w)
   R r[12];
   R ymin, ymax;  // cylinder / cone extents
-  R pad0, pad1;
+  R root;        // instance: root node of the mesh's tree (a whole number)
+  R pad1;
 };
 
 // Triangle record: the three vertices as the f32 values the host handed over (src/triangle.rs:10-12),
@@ -109,9 +117,13 @@ struct DevScene {
   const DevTri* tri;              // n_prims (valid for triangle kinds)
   const DevTriNormals<R>* trin;   // n_prims (valid for triangle kinds)
   const DevMaterial<R>* materials;
-  int32_t n_nodes, n_bounded, n_prims, n_materials;
+  // prims [0, n_bounded) are the leaves of the top tree, [n_bounded, n_top) the prims every ray tests, [n_top, n_prims)
+  // the triangles of the instanced meshes
+  int32_t n_nodes, n_bounded, n_top, n_materials;
   float box_abs_max;  // largest |coordinate| of any BVH box: scales the error bound of the slab test
   R light_pos[3], light_int[3];
+  const int32_t* inst_of;         // n_prims when the scene has instances: the instance prim of a PF_INSTANCED triangle
+  int32_t n_prims;
 };
 
 // What differs between the frames of one batch: the view.  (Image size, tiling and rank are shared.)
@@ -190,6 +202,9 @@ struct HostPrim {
   double n1[3], n2[3], n3[3], nf[3];
   double lo[3], hi[3];
   bool bounded;
+  int32_t inst_index;  // instance prim: which instance; triangle of an instanced mesh: its instance; -1 otherwise
+  int32_t blas_root;   // instance prim: root node of its mesh's tree
+  int32_t inst_prim;   // triangle of an instanced mesh: prim id of its instance
 };
 
 struct HostNode {
@@ -198,8 +213,10 @@ struct HostNode {
 };
 
 struct HostScene {
-  std::vector<HostPrim> prims;  // final order: BVH leaf order, then the unbounded prims
+  std::vector<HostPrim> prims;  // final order: leaf order of the top tree, the unbounded prims, then mesh after instanced mesh
   int32_t n_bounded = 0;
+  int32_t n_top = 0;        // bounded + unbounded
+  int32_t n_instances = 0;
   std::vector<HostNode> nodes;
   int32_t max_depth = 0;  // most traversal-stack entries any descent can need
   std::vector<rt355_material> materials;

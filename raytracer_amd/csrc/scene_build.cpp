@@ -217,6 +217,107 @@ int32_t encode_leaf(int first, int count, bool tri_only) {
   return ~(int32_t)((uint32_t)first | (tri_only ? LEAF_TRI_BIT : 0u) | ((uint32_t)count << 26));
 }
 
+// Builds the 4-wide BVH of `prims` (bounded prims, any order) and appends it to `out`: the prims, reordered into leaf
+// order, go to out.prims (their first index is the value of out.prims.size() on entry), the nodes to out.nodes, root
+// first.  Returns the index of the root node, or -1 when there is no prim; `need_out` receives the number of stack
+// entries a descent through this tree can need.
+int append_tree(std::vector<HostPrim>& prims, HostScene& out, int& need_out) {
+  need_out = 0;
+  if (prims.empty()) return -1;
+  const int prim_base = (int)out.prims.size();
+  const int node_base = (int)out.nodes.size();
+  Builder B(prims);
+  size_t nb = prims.size();
+  B.boxes.resize(nb), B.cx.resize(nb), B.cy.resize(nb), B.cz.resize(nb), B.order.resize(nb), B.cost.resize(nb);
+  for (size_t i = 0; i < nb; ++i) {
+    for (int k = 0; k < 3; ++k) B.boxes[i].lo[k] = prims[i].lo[k], B.boxes[i].hi[k] = prims[i].hi[k];
+    B.cx[i] = 0.5 * (prims[i].lo[0] + prims[i].hi[0]);
+    B.cy[i] = 0.5 * (prims[i].lo[1] + prims[i].hi[1]);
+    B.cz[i] = 0.5 * (prims[i].lo[2] + prims[i].hi[2]);
+    B.order[i] = (int)i;
+    const int kind = prims[i].flags & PF_KIND_MASK;
+    const bool plain_tri = kind >= RT355_TRIANGLE && (prims[i].flags & PF_IDENTITY);
+    // an instance costs the ray's trip to object space plus a descent into its own tree
+    B.cost[i] = plain_tri ? 1.0 : kind == RT355_INSTANCE ? 16.0 : 4.0;
+  }
+  B.nodes.reserve(2 * nb);
+  int root = B.build(0, (int)nb, 0);
+  // reorder prims into leaf order
+  for (size_t k = 0; k < nb; ++k) out.prims.push_back(prims[B.order[k]]);
+  // Collapse the binary tree into 4-wide nodes: a wide node starts from the two children of a binary
+  // inner node and keeps replacing its largest inner child by that child's two children until it has
+  // four, or only leaves.  Device nodes are emitted in DFS order.
+  auto leaf_ref = [&](int first, int count) -> int32_t {
+    bool tri_only = count > 0;
+    for (int k = first; k < first + count; ++k) {
+      const HostPrim& q = out.prims[prim_base + k];
+      if ((q.flags & PF_KIND_MASK) < RT355_TRIANGLE || !(q.flags & PF_IDENTITY)) tri_only = false;
+    }
+    return encode_leaf(prim_base + first, count, tri_only);
+  };
+  auto kids_of = [&](int bn) {
+    std::vector<int> kids{B.nodes[bn].left, B.nodes[bn].right};
+    while ((int)kids.size() < BVH_WIDTH) {
+      int pick = -1;
+      double best = -1.0;
+      for (int k = 0; k < (int)kids.size(); ++k)
+        if (B.nodes[kids[k]].left >= 0 && B.nodes[kids[k]].box.area() > best) best = B.nodes[kids[k]].box.area(), pick = k;
+      if (pick < 0) break;
+      const int bn2 = kids[pick];
+      kids[pick] = B.nodes[bn2].left;
+      kids.insert(kids.begin() + pick + 1, B.nodes[bn2].right);
+    }
+    return kids;
+  };
+  auto empty_slot = [](HostNode& hn, int k) {
+    for (int a = 0; a < 3; ++a) hn.lo[k][a] = INFINITY, hn.hi[k][a] = -INFINITY;
+    hn.c[k] = encode_leaf(0, 0, false);
+  };
+  if (B.nodes[root].left < 0) {
+    // the root is a leaf: wrap it in one node with a single child
+    HostNode hn;
+    for (int k = 0; k < BVH_WIDTH; ++k) empty_slot(hn, k);
+    for (int a = 0; a < 3; ++a) hn.lo[0][a] = B.nodes[root].box.lo[a], hn.hi[0][a] = B.nodes[root].box.hi[a];
+    hn.c[0] = leaf_ref(B.nodes[root].first, B.nodes[root].count);
+    out.nodes.push_back(hn);
+    need_out = 1;
+  } else {
+    // wide nodes in DFS order: (binary node it was grown from, its children)
+    struct Wide { int bn; std::vector<int> kids; };
+    std::vector<Wide> wide;
+    std::vector<int> map(B.nodes.size(), -1);
+    std::vector<int> stack{root};
+    while (!stack.empty()) {
+      int bn = stack.back();
+      stack.pop_back();
+      map[bn] = (int)wide.size();
+      wide.push_back({bn, kids_of(bn)});
+      const std::vector<int>& kids = wide.back().kids;
+      for (int k = (int)kids.size() - 1; k >= 0; --k)
+        if (B.nodes[kids[k]].left >= 0) stack.push_back(kids[k]);
+    }
+    std::vector<int> need(wide.size(), 0);  // stack entries a descent through this node can need
+    for (int w = (int)wide.size() - 1; w >= 0; --w) {  // children come after their parent in DFS order
+      int deepest = 0;
+      for (int kid : wide[w].kids)
+        if (B.nodes[kid].left >= 0) deepest = std::max(deepest, need[map[kid]]);
+      need[w] = (int)wide[w].kids.size() - 1 + deepest;
+    }
+    need_out = need[0] + 1;
+    for (const Wide& w : wide) {
+      HostNode hn;
+      for (int k = 0; k < BVH_WIDTH; ++k) empty_slot(hn, k);
+      for (int k = 0; k < (int)w.kids.size(); ++k) {
+        const BuildNode& c = B.nodes[w.kids[k]];
+        for (int a = 0; a < 3; ++a) hn.lo[k][a] = c.box.lo[a], hn.hi[k][a] = c.box.hi[a];
+        hn.c[k] = c.left < 0 ? leaf_ref(c.first, c.count) : node_base + map[w.kids[k]];
+      }
+      out.nodes.push_back(hn);
+    }
+  }
+  return node_base;
+}
+
 }  // namespace
 
 int build_host_scene(const rt355_shape_desc* shapes, size_t n, double pad_rel, int64_t cone_exact_limit, HostScene& out, char* err, size_t errlen) {
@@ -232,6 +333,34 @@ int build_host_scene(const rt355_shape_desc* shapes, size_t n, double pad_rel, i
   };
   std::map<std::string, int> mat_index;
   std::vector<HostPrim> bounded, unbounded;
+  // Instanced meshes: a run of triangles that share one transformation other than the identity -- what the reference's
+  // flattening leaves of a group with a mesh under it (src/group.rs:130-168 folds the group's transformation into
+  // every triangle).  Such a run stays in object space under a tree of its own; rays are taken there once per
+  // instance instead of once per triangle.  Shorter runs are not worth a second descent.
+  struct Instance {
+    size_t first_shape;
+    std::vector<HostPrim> tris;
+  };
+  std::vector<Instance> instances;
+  std::vector<int32_t> instance_of(n, -1);
+  {
+    const size_t min_run = getenv("RT355_INSTANCE_MIN") ? (size_t)std::max(1, atoi(getenv("RT355_INSTANCE_MIN"))) : 16;
+    auto is_tri = [&](size_t i) { return shapes[i].kind == RT355_TRIANGLE || shapes[i].kind == RT355_SMOOTH_TRIANGLE; };
+    for (size_t i = 0; i < n;) {
+      if (!is_tri(i) || is_identity(shapes[i].m)) {
+        ++i;
+        continue;
+      }
+      size_t j = i + 1, count = 1;
+      while (j < n && (shapes[j].kind == RT355_GROUP || (is_tri(j) && memcmp(shapes[j].m, shapes[i].m, sizeof(shapes[i].m)) == 0))) count += shapes[j].kind != RT355_GROUP, ++j;
+      if (count >= min_run) {
+        for (size_t k = i; k < j; ++k)
+          if (shapes[k].kind != RT355_GROUP) instance_of[k] = (int32_t)instances.size();
+        instances.push_back({i, {}});
+      }
+      i = j;
+    }
+  }
   for (size_t i = 0; i < n; ++i) {
     const rt355_shape_desc& d = shapes[i];
     if (d.kind < 0 || d.kind > RT355_SMOOTH_TRIANGLE) return fail("unknown kind", i);
@@ -239,6 +368,7 @@ int build_host_scene(const rt355_shape_desc* shapes, size_t n, double pad_rel, i
     HostPrim p;
     memset(&p, 0, sizeof(p));
     p.shape = (int32_t)i;
+    p.inst_index = instance_of[i], p.blas_root = -1, p.inst_prim = -1;
     for (int k = 0; k < 16; ++k)
       if (!std::isfinite(d.m[k])) return fail("non-finite transformation", i);
     if (!affine_inverse(d.m, p.inv)) return fail("transformation is singular or not affine", i);
@@ -308,9 +438,14 @@ int build_host_scene(const rt355_shape_desc* shapes, size_t n, double pad_rel, i
         double len = std::sqrt(nx * nx + ny * ny + nz * nz);
         p.nf[0] = nx / len, p.nf[1] = ny / len, p.nf[2] = nz / len;  // zero-area triangle: NaN, as in the reference
         double q1[3] = {d.p1[0], d.p1[1], d.p1[2]}, q2[3] = {d.p2[0], d.p2[1], d.p2[2]}, q3[3] = {d.p3[0], d.p3[1], d.p3[2]}, w[3];
-        xf_point(d.m, q1, w), b.grow(w);
-        xf_point(d.m, q2, w), b.grow(w);
-        xf_point(d.m, q3, w), b.grow(w);
+        if (p.inst_index >= 0) {  // kept in object space: the mesh's own tree is built over the vertices as they are
+          p.flags |= PF_IDENTITY | PF_INSTANCED;
+          b.grow(q1), b.grow(q2), b.grow(q3);
+        } else {
+          xf_point(d.m, q1, w), b.grow(w);
+          xf_point(d.m, q2, w), b.grow(w);
+          xf_point(d.m, q3, w), b.grow(w);
+        }
         break;
       }
     }
@@ -324,113 +459,67 @@ int build_host_scene(const rt355_shape_desc* shapes, size_t n, double pad_rel, i
         double pad = pad_rel * mag + 1e-300;
         p.lo[k] = b.lo[k] - pad, p.hi[k] = b.hi[k] + pad;
       }
-      bounded.push_back(p);
+      if (p.inst_index >= 0) instances[p.inst_index].tris.push_back(p); else bounded.push_back(p);
     } else {
+      if (p.inst_index >= 0) return fail("triangle of an instanced mesh has no finite bound", i);
       unbounded.push_back(p);
     }
   }
-  if (out.materials.size() >= (1u << 22)) {
+  // one prim of the top tree per instance: the world-space box of the mesh's object-space box
+  for (size_t k = 0; k < instances.size(); ++k) {
+    const Instance& in = instances[k];
+    const rt355_shape_desc& d = shapes[in.first_shape];
+    HostPrim p;
+    memset(&p, 0, sizeof(p));
+    p.shape = (int32_t)in.first_shape;
+    p.flags = RT355_INSTANCE;
+    p.inst_index = (int32_t)k, p.blas_root = -1, p.inst_prim = -1;
+    if (!affine_inverse(d.m, p.inv)) return fail("transformation is singular or not affine", in.first_shape);
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (const HostPrim& t : in.tris)
+      for (int a = 0; a < 3; ++a) lo[a] = std::min(lo[a], t.lo[a]), hi[a] = std::max(hi[a], t.hi[a]);
+    Box b;
+    box_of_local(d.m, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], b);
+    p.bounded = true;
+    for (int a = 0; a < 3; ++a) {
+      if (!std::isfinite(b.lo[a]) || !std::isfinite(b.hi[a])) return fail("instanced mesh has no finite bound", in.first_shape);
+      double mag = std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])) + (b.hi[a] - b.lo[a]);
+      double pad = pad_rel * mag + 1e-300;
+      p.lo[a] = b.lo[a] - pad, p.hi[a] = b.hi[a] + pad;
+    }
+    bounded.push_back(p);
+  }
+  if (out.materials.size() >= (1u << 21)) {
     snprintf(err, errlen, "too many distinct materials");
     return RT355_EINVAL;
   }
-  if (bounded.size() >= LEAF_FIRST_MASK) {
+  if (n >= LEAF_FIRST_MASK) {
     snprintf(err, errlen, "too many shapes");
     return RT355_EINVAL;
   }
 
   // ---- BVH over the bounded prims ---------------------------------------------------------------
+  // The top tree first (root = node 0, prims [0, n_bounded)), then the prims no box holds, then the tree of every
+  // instanced mesh with its triangles behind it.
   out.n_bounded = (int32_t)bounded.size();
-  if (!bounded.empty()) {
-    Builder B(bounded);
-    size_t nb = bounded.size();
-    B.boxes.resize(nb), B.cx.resize(nb), B.cy.resize(nb), B.cz.resize(nb), B.order.resize(nb), B.cost.resize(nb);
-    for (size_t i = 0; i < nb; ++i) {
-      for (int k = 0; k < 3; ++k) B.boxes[i].lo[k] = bounded[i].lo[k], B.boxes[i].hi[k] = bounded[i].hi[k];
-      B.cx[i] = 0.5 * (bounded[i].lo[0] + bounded[i].hi[0]);
-      B.cy[i] = 0.5 * (bounded[i].lo[1] + bounded[i].hi[1]);
-      B.cz[i] = 0.5 * (bounded[i].lo[2] + bounded[i].hi[2]);
-      B.order[i] = (int)i;
-      const bool plain_tri = (bounded[i].flags & PF_KIND_MASK) >= RT355_TRIANGLE && (bounded[i].flags & PF_IDENTITY);
-      B.cost[i] = plain_tri ? 1.0 : 4.0;
-    }
-    B.nodes.reserve(2 * nb);
-    int root = B.build(0, (int)nb, 0);
-    // reorder prims into leaf order
-    out.prims.reserve(nb + unbounded.size());
-    for (size_t k = 0; k < nb; ++k) out.prims.push_back(bounded[B.order[k]]);
-    // Collapse the binary tree into 4-wide nodes: a wide node starts from the two children of a binary
-    // inner node and keeps replacing its largest inner child by that child's two children until it has
-    // four, or only leaves.  Device nodes are emitted in DFS order.
-    auto leaf_ref = [&](int first, int count) -> int32_t {
-      bool tri_only = count > 0;
-      for (int k = first; k < first + count; ++k) {
-        const HostPrim& q = out.prims[k];
-        if ((q.flags & PF_KIND_MASK) < RT355_TRIANGLE || !(q.flags & PF_IDENTITY)) tri_only = false;
-      }
-      return encode_leaf(first, count, tri_only);
-    };
-    auto kids_of = [&](int bn) {
-      std::vector<int> kids{B.nodes[bn].left, B.nodes[bn].right};
-      while ((int)kids.size() < BVH_WIDTH) {
-        int pick = -1;
-        double best = -1.0;
-        for (int k = 0; k < (int)kids.size(); ++k)
-          if (B.nodes[kids[k]].left >= 0 && B.nodes[kids[k]].box.area() > best) best = B.nodes[kids[k]].box.area(), pick = k;
-        if (pick < 0) break;
-        const int bn2 = kids[pick];
-        kids[pick] = B.nodes[bn2].left;
-        kids.insert(kids.begin() + pick + 1, B.nodes[bn2].right);
-      }
-      return kids;
-    };
-    auto empty_slot = [](HostNode& hn, int k) {
-      for (int a = 0; a < 3; ++a) hn.lo[k][a] = INFINITY, hn.hi[k][a] = -INFINITY;
-      hn.c[k] = encode_leaf(0, 0, false);
-    };
-    if (B.nodes[root].left < 0) {
-      // the root is a leaf: wrap it in one node with a single child
-      HostNode hn;
-      for (int k = 0; k < BVH_WIDTH; ++k) empty_slot(hn, k);
-      for (int a = 0; a < 3; ++a) hn.lo[0][a] = B.nodes[root].box.lo[a], hn.hi[0][a] = B.nodes[root].box.hi[a];
-      hn.c[0] = leaf_ref(B.nodes[root].first, B.nodes[root].count);
-      out.nodes.push_back(hn);
-      out.max_depth = 1;
-    } else {
-      // wide nodes in DFS order: (binary node it was grown from, its children)
-      struct Wide { int bn; std::vector<int> kids; };
-      std::vector<Wide> wide;
-      std::vector<int> map(B.nodes.size(), -1);
-      std::vector<int> stack{root};
-      while (!stack.empty()) {
-        int bn = stack.back();
-        stack.pop_back();
-        map[bn] = (int)wide.size();
-        wide.push_back({bn, kids_of(bn)});
-        const std::vector<int>& kids = wide.back().kids;
-        for (int k = (int)kids.size() - 1; k >= 0; --k)
-          if (B.nodes[kids[k]].left >= 0) stack.push_back(kids[k]);
-      }
-      std::vector<int> need(wide.size(), 0);  // stack entries a descent through this node can need
-      for (int w = (int)wide.size() - 1; w >= 0; --w) {  // children come after their parent in DFS order
-        int deepest = 0;
-        for (int kid : wide[w].kids)
-          if (B.nodes[kid].left >= 0) deepest = std::max(deepest, need[map[kid]]);
-        need[w] = (int)wide[w].kids.size() - 1 + deepest;
-      }
-      out.max_depth = need[0] + 1;
-      for (const Wide& w : wide) {
-        HostNode hn;
-        for (int k = 0; k < BVH_WIDTH; ++k) empty_slot(hn, k);
-        for (int k = 0; k < (int)w.kids.size(); ++k) {
-          const BuildNode& c = B.nodes[w.kids[k]];
-          for (int a = 0; a < 3; ++a) hn.lo[k][a] = c.box.lo[a], hn.hi[k][a] = c.box.hi[a];
-          hn.c[k] = c.left < 0 ? leaf_ref(c.first, c.count) : map[w.kids[k]];
-        }
-        out.nodes.push_back(hn);
-      }
-    }
-  }
+  int need_top = 0, need_mesh = 0;
+  append_tree(bounded, out, need_top);
   for (auto& p : unbounded) out.prims.push_back(p);
+  out.n_top = (int32_t)out.prims.size();
+  out.n_instances = (int32_t)instances.size();
+  std::vector<int> inst_prim(instances.size(), -1);  // where each instance's prim ended up in the top tree's leaf order
+  for (int q = 0; q < out.n_bounded; ++q)
+    if ((out.prims[q].flags & PF_KIND_MASK) == RT355_INSTANCE) inst_prim[out.prims[q].inst_index] = q;
+  for (size_t k = 0; k < instances.size(); ++k) {
+    int need = 0;
+    const size_t first = out.prims.size();
+    const int root = append_tree(instances[k].tris, out, need);
+    need_mesh = std::max(need_mesh, need);
+    out.prims[inst_prim[k]].blas_root = root;
+    for (size_t q = first; q < out.prims.size(); ++q) out.prims[q].inst_prim = inst_prim[k];
+  }
+  // a ray inside a mesh's tree still has the top tree's entries below it on the stack
+  out.max_depth = need_top + need_mesh;
   if (out.max_depth > STACK_DEPTH - 2) {
     snprintf(err, errlen, "BVH needs a deeper traversal stack than the kernels have (%d)", out.max_depth);
     return RT355_EINVAL;
@@ -438,81 +527,104 @@ int build_host_scene(const rt355_shape_desc* shapes, size_t n, double pad_rel, i
   return RT355_OK;
 }
 
-// Structural check of a built scene, on the host: every bounded prim sits in exactly one leaf, every child
-// box encloses the boxes of all prims beneath it, inner nodes are reachable exactly once, and no descent can
-// need more stack entries than max_depth says.  Returns 0 or RT355_EINVAL with a message.
+// Structural check of a built scene, on the host: every bounded prim sits in exactly one leaf of its tree (the top
+// tree, or the tree of the instanced mesh it belongs to), every child box encloses the boxes of all prims beneath it,
+// inner nodes are reachable exactly once, every instance points at the root of a tree that holds exactly its
+// triangles, and no descent can need more stack entries than max_depth says.  Returns 0 or RT355_EINVAL with a message.
 int verify_host_scene(const HostScene& hs, char* err, size_t errlen) {
-  const int nb = hs.n_bounded;
+  const int nb = hs.n_bounded, np = (int)hs.prims.size();
   if (hs.nodes.empty()) {
-    if (nb != 0) { snprintf(err, errlen, "bounded prims but no nodes"); return RT355_EINVAL; }
+    if (nb != 0 || hs.n_top != np) { snprintf(err, errlen, "bounded prims but no nodes"); return RT355_EINVAL; }
     return RT355_OK;
   }
-  std::vector<int> seen_prim(nb, 0), seen_node(hs.nodes.size(), 0);
-  struct Item { int node; int stack; };
-  std::vector<Item> todo{{0, 0}};
-  int worst = 0;
-  seen_node[0] = 1;
-  // boxes of the subtree under (node, child) are checked against that child's box by a second walk
-  std::vector<std::pair<int, int>> sub;
-  while (!todo.empty()) {
-    Item it = todo.back();
-    todo.pop_back();
-    const HostNode& n = hs.nodes[it.node];
-    int kids = 0;
-    for (int k = 0; k < BVH_WIDTH; ++k) kids += n.c[k] != -1;
-    if (kids == 0) { snprintf(err, errlen, "node %d has no children", it.node); return RT355_EINVAL; }
-    const int stack_here = it.stack + kids - 1;
-    worst = std::max(worst, stack_here);
-    for (int k = 0; k < BVH_WIDTH; ++k) {
-      if (n.c[k] == -1) {
-        if (!(n.lo[k][0] > n.hi[k][0])) { snprintf(err, errlen, "empty slot of node %d has a box", it.node); return RT355_EINVAL; }
-        continue;
-      }
-      // collect the prims beneath this child
-      sub.clear();
-      std::vector<int> walk{n.c[k]};
-      while (!walk.empty()) {
-        int c = walk.back();
-        walk.pop_back();
-        if (c >= 0) {
-          if (c >= (int)hs.nodes.size()) { snprintf(err, errlen, "child index out of range"); return RT355_EINVAL; }
-          for (int j = 0; j < BVH_WIDTH; ++j)
-            if (hs.nodes[c].c[j] != -1) walk.push_back(hs.nodes[c].c[j]);
+  std::vector<int> seen_prim(np, 0), seen_node(hs.nodes.size(), 0);
+  // walks the tree under `root`, whose leaves must lie in [lo, hi) and, for a mesh's tree, belong to instance prim `owner`
+  auto walk_tree = [&](int root, int lo, int hi, int owner, int& worst) -> int {
+    struct Item { int node; int stack; };
+    if (root < 0 || root >= (int)hs.nodes.size()) { snprintf(err, errlen, "root out of range"); return RT355_EINVAL; }
+    std::vector<Item> todo{{root, 0}};
+    worst = 0;
+    if (seen_node[root]++) { snprintf(err, errlen, "root %d reached twice", root); return RT355_EINVAL; }
+    std::vector<std::pair<int, int>> sub;
+    while (!todo.empty()) {
+      Item it = todo.back();
+      todo.pop_back();
+      const HostNode& n = hs.nodes[it.node];
+      int kids = 0;
+      for (int k = 0; k < BVH_WIDTH; ++k) kids += n.c[k] != -1;
+      if (kids == 0) { snprintf(err, errlen, "node %d has no children", it.node); return RT355_EINVAL; }
+      worst = std::max(worst, it.stack + kids - 1);
+      for (int k = 0; k < BVH_WIDTH; ++k) {
+        if (n.c[k] == -1) {
+          if (!(n.lo[k][0] > n.hi[k][0])) { snprintf(err, errlen, "empty slot of node %d has a box", it.node); return RT355_EINVAL; }
+          continue;
+        }
+        // collect the prims beneath this child
+        sub.clear();
+        std::vector<int> walk{n.c[k]};
+        while (!walk.empty()) {
+          int c = walk.back();
+          walk.pop_back();
+          if (c >= 0) {
+            if (c >= (int)hs.nodes.size()) { snprintf(err, errlen, "child index out of range"); return RT355_EINVAL; }
+            for (int j = 0; j < BVH_WIDTH; ++j)
+              if (hs.nodes[c].c[j] != -1) walk.push_back(hs.nodes[c].c[j]);
+          } else {
+            const uint32_t leaf = (uint32_t)~c;
+            sub.push_back({(int)(leaf & LEAF_FIRST_MASK), (int)(leaf >> 26)});
+          }
+        }
+        for (auto& fc : sub)
+          for (int q = fc.first; q < fc.first + fc.second; ++q) {
+            if (q < lo || q >= hi) { snprintf(err, errlen, "leaf range out of bounds"); return RT355_EINVAL; }
+            const HostPrim& pr = hs.prims[q];
+            if (pr.inst_prim != owner) { snprintf(err, errlen, "prim %d sits in the tree of another owner", q); return RT355_EINVAL; }
+            for (int a = 0; a < 3; ++a)
+              if (pr.lo[a] < n.lo[k][a] || pr.hi[a] > n.hi[k][a]) {
+                snprintf(err, errlen, "prim %d sticks out of child %d of node %d", q, k, it.node);
+                return RT355_EINVAL;
+              }
+          }
+        if (n.c[k] >= 0) {
+          if (seen_node[n.c[k]]++) { snprintf(err, errlen, "node %d reached twice", n.c[k]); return RT355_EINVAL; }
+          todo.push_back({n.c[k], it.stack + kids - 1});
         } else {
-          const uint32_t leaf = (uint32_t)~c;
-          sub.push_back({(int)(leaf & LEAF_FIRST_MASK), (int)(leaf >> 26)});
-        }
-      }
-      for (auto& fc : sub)
-        for (int q = fc.first; q < fc.first + fc.second; ++q) {
-          if (q < 0 || q >= nb) { snprintf(err, errlen, "leaf range out of bounds"); return RT355_EINVAL; }
-          const HostPrim& pr = hs.prims[q];
-          for (int a = 0; a < 3; ++a)
-            if (pr.lo[a] < n.lo[k][a] || pr.hi[a] > n.hi[k][a]) {
-              snprintf(err, errlen, "prim %d sticks out of child %d of node %d", q, k, it.node);
-              return RT355_EINVAL;
-            }
-        }
-      if (n.c[k] >= 0) {
-        if (seen_node[n.c[k]]++) { snprintf(err, errlen, "node %d reached twice", n.c[k]); return RT355_EINVAL; }
-        todo.push_back({n.c[k], it.stack + kids - 1});
-      } else {
-        const uint32_t leaf = (uint32_t)~n.c[k];
-        const int first = (int)(leaf & LEAF_FIRST_MASK), count = (int)(leaf >> 26);
-        const bool tri_only = (leaf & LEAF_TRI_BIT) != 0;
-        for (int q = first; q < first + count; ++q) {
-          seen_prim[q]++;
-          const bool is_tri = (hs.prims[q].flags & PF_KIND_MASK) >= RT355_TRIANGLE && (hs.prims[q].flags & PF_IDENTITY);
-          if (tri_only && !is_tri) { snprintf(err, errlen, "triangle-only leaf holds prim %d of another kind", q); return RT355_EINVAL; }
+          const uint32_t leaf = (uint32_t)~n.c[k];
+          const int first = (int)(leaf & LEAF_FIRST_MASK), count = (int)(leaf >> 26);
+          const bool tri_only = (leaf & LEAF_TRI_BIT) != 0;
+          for (int q = first; q < first + count; ++q) {
+            seen_prim[q]++;
+            const bool is_tri = (hs.prims[q].flags & PF_KIND_MASK) >= RT355_TRIANGLE && (hs.prims[q].flags & PF_IDENTITY);
+            if (tri_only && !is_tri) { snprintf(err, errlen, "triangle-only leaf holds prim %d of another kind", q); return RT355_EINVAL; }
+            if (owner >= 0 && !tri_only) { snprintf(err, errlen, "a mesh's tree holds a leaf that is not triangles only"); return RT355_EINVAL; }
+          }
         }
       }
     }
+    return RT355_OK;
+  };
+  int worst_top = 0, worst_mesh = 0, n_inst = 0;
+  if (nb > 0) {
+    if (int rc = walk_tree(0, 0, nb, -1, worst_top)) return rc;
+    worst_top += 1;
   }
-  for (int q = 0; q < nb; ++q)
-    if (seen_prim[q] != 1) { snprintf(err, errlen, "prim %d is in %d leaves", q, seen_prim[q]); return RT355_EINVAL; }
+  for (int q = 0; q < nb; ++q) {
+    const HostPrim& pr = hs.prims[q];
+    if ((pr.flags & PF_KIND_MASK) != RT355_INSTANCE) continue;
+    ++n_inst;
+    int worst = 0;
+    if (int rc = walk_tree(pr.blas_root, hs.n_top, np, q, worst)) return rc;
+    worst_mesh = std::max(worst_mesh, worst + 1);
+  }
+  if (n_inst != hs.n_instances) { snprintf(err, errlen, "%d instance prims, %d instances recorded", n_inst, hs.n_instances); return RT355_EINVAL; }
+  for (int q = 0; q < np; ++q) {
+    const bool in_tree = q < nb || q >= hs.n_top;
+    if (seen_prim[q] != (in_tree ? 1 : 0)) { snprintf(err, errlen, "prim %d is in %d leaves", q, seen_prim[q]); return RT355_EINVAL; }
+    if (q >= hs.n_top && !(hs.prims[q].flags & PF_INSTANCED)) { snprintf(err, errlen, "prim %d behind the top prims is not part of an instance", q); return RT355_EINVAL; }
+  }
   for (size_t i = 0; i < hs.nodes.size(); ++i)
     if (!seen_node[i]) { snprintf(err, errlen, "node %zu is unreachable", i); return RT355_EINVAL; }
-  if (worst + 1 > hs.max_depth) { snprintf(err, errlen, "a descent needs %d stack entries, recorded %d", worst + 1, hs.max_depth); return RT355_EINVAL; }
+  if (worst_top + worst_mesh > hs.max_depth) { snprintf(err, errlen, "a descent needs %d stack entries, recorded %d", worst_top + worst_mesh, hs.max_depth); return RT355_EINVAL; }
   return RT355_OK;
 }
 

@@ -108,6 +108,42 @@ def north_star(width=1920, height=1080, mesh="teapot-high.obj"):
     return world, _camera(width, height, PI / 3.0, (0.0, 25.0, 45.0), (0.0, 7.0, 0.0), (0.0, 1.0, 0.0))
 
 
+def teapot_field(width=1920, height=1080, mesh="teapot-high.obj", n_side=4, through_groups=False):
+    """n_side x n_side copies of one teapot mesh, each under a group with a transformation of its own (placed on a grid,
+    turned about Y, scaled), on a reflective floor: the reference's way of instancing a mesh -- Wavefront::parse
+    puts the triangles under a group (src/wavefront.rs:41-44) and Scene::to_transformed_shapes folds the group's
+    transformation into every triangle (src/group.rs:130-168, used at src/main.rs:869-881).  The World holds the
+    flattened list: runs of triangles that share one transformation.  `through_groups` builds the tree with Node
+    objects and flattens it with group.to_transformed_shapes (small meshes); otherwise the same list is made directly."""
+    from . import group as grp
+    tris = _teapot(mesh, True)
+    floor = Shape.Plane(None, Material(color=(0.9, 0.9, 1.0), specular=0.3, reflective=0.25,
+                                       pattern=Pattern.Checker((1, 1, 1), (0.2, 0.2, 0.25))))
+    rnd = _splitmix64(3 * n_side * n_side, seed=0x517)
+    shapes = [floor]
+    root = grp.Node(Shape.Group())
+    pitch = 52.0
+    for k in range(n_side * n_side):
+        gx, gz = k % n_side, k // n_side
+        t = (mx.translation((gx - (n_side - 1) / 2.0) * pitch, 0.0, (gz - (n_side - 1) / 2.0) * pitch) @ mx.rotation_y(2.0 * PI * float(rnd[3 * k]))
+             @ mx.scaling(*([0.7 + 0.6 * float(rnd[3 * k + 1])] * 3))).astype(np.float32)
+        if through_groups:
+            g = root.add(Shape.Group(t))
+            for tri in tris:
+                g.add(tri.copy())
+        else:
+            shapes.append(Shape.Group(t))
+            for tri in tris:
+                c = tri.copy()
+                c.set_transform(t)
+                shapes.append(c)
+    if through_groups:
+        shapes += grp.to_transformed_shapes(root)
+    world = World(PointLight((-60.0, 120.0, 90.0), (1, 1, 1)), shapes)
+    d = pitch * n_side
+    return world, _camera(width, height, PI / 3.0, (0.15 * d, 0.55 * d, 1.0 * d), (0.0, 5.0, 0.0), (0.0, 1.0, 0.0))
+
+
 def glass(width=1920, height=1080):
     """Config 4: Schlick + recursion depth 5 with checker / ring / stripe patterns.  Patterns and walls
     follow src/main.rs:389-535; the nested glass-with-air-bubble case follows the n1/n2 test
@@ -290,4 +326,5 @@ CONFIGS = {
     "glass": glass,
     "stress": stress,
     "north_star": north_star,
+    "teapot_field": teapot_field,
 }

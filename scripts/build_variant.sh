@@ -3,4 +3,9 @@
 # (select it at run time with RT355_LIB=build_exp/lib<name>.so)
 name=$1; shift
 cd "$(dirname "$0")/.." && mkdir -p build_exp
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared "$@" -o build_exp/lib$name.so raytracer_amd/csrc/rt355.hip raytracer_amd/csrc/scene_build.cpp raytracer_amd/csrc/rt355_multi.cpp -ldl -lpthread
+python3 - "$name" "$@" <<'PY'
+import sys
+import __graft_entry__ as g
+name, flags = sys.argv[1], sys.argv[2:]
+g.build_library(f"build_exp/lib{name}.so", extra_flags=flags, obj_dir=f"build_exp/obj_{name}", force=True)
+PY

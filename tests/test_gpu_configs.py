@@ -464,3 +464,113 @@ def test_cube_slab_test_sees_the_sign_of_a_zero_direction(oracle, real_bits):
             else:
                 n_miss += 1
     assert n_miss > 0 and n_hit > 0  # both outcomes occur: the sign of the zero decides
+
+
+# ------------------------------------------------------------------------------------------ instanced meshes
+def _instancing(on):
+    """RT355_INSTANCE_MIN is read at every upload: a run of at least that many triangles sharing one non-identity
+    transformation becomes one instance over an object-space tree."""
+    if on:
+        os.environ.pop("RT355_INSTANCE_MIN", None)
+    else:
+        os.environ["RT355_INSTANCE_MIN"] = str(1 << 30)
+
+
+@pytest.mark.parametrize("real_bits", [64, 32])
+def test_group_transformed_meshes_as_instances(oracle, real_bits):
+    """16 copies of teapot-low.obj under 16 groups with transformations of their own, flattened the reference's way
+    (src/group.rs:130-168): the upload turns every copy into one instance with an object-space tree below a top-level
+    tree.  Nearest hits on 10^5 rays against World::intersect + hit, the image against the oracle, and both bit for
+    bit against the same scene uploaded with instancing switched off (every triangle a world-space leaf)."""
+    import torch
+    w, h = 160, 90
+    world, cam = scenes.teapot_field(w, h, "teapot-low.obj", 4, through_groups=True)
+    direct, _ = scenes.teapot_field(w, h, "teapot-low.obj", 4, through_groups=False)
+    assert world.n_shapes() == direct.n_shapes() + 1  # the root group is one more inert entry
+    dev = Device.get(0, real_bits)
+    big = Camera(1000, 600, float(cam.field_of_view), cam.transform)
+    _, rays = camera_sample_rays(oracle, big, 50000, 41)
+    rays = np.concatenate([rays, scattered_rays(50000, 42, (-110, 0.2, -110), (110, 30, 110))])
+    try:
+        _instancing(True)
+        scene = dev.upload(world)
+        info = scene.info()
+        assert info["bounded"] == 16 and info["unbounded"] == 1, info  # 16 instances + the floor
+        bad, n, ties, hits = compare_hits(oracle, world, scene, rays, real_bits)
+        print(f"teapot field f{real_bits}: {bad} of {n} rays outside the bar, {ties} ties excluded, {hits} hits")
+        assert bad == 0 and hits > 30000 and n > 90000
+        t_inst, i_inst = scene.trace(rays)
+        st = Stats()
+        img_inst = scene.render(cam, 5, st).pixels.copy()
+        scene.close()
+        _instancing(False)
+        scene = dev.upload(world)
+        assert scene.info()["bounded"] == 16 * 240
+        t_flat, i_flat = scene.trace(rays)
+        img_flat = scene.render(cam, 5).pixels.copy()
+        scene.close()
+    finally:
+        _instancing(True)
+    diff = np.flatnonzero(~((t_inst == t_flat) | (np.isnan(t_inst) & np.isnan(t_flat))))
+    print(f"t differs on {len(diff)} rays", [(int(k), int(i_inst[k]), float(t_inst[k]), float(t_flat[k])) for k in diff[:8]])
+    assert np.array_equal(i_inst, i_flat) and len(diff) == 0
+    assert np.array_equal(img_inst, img_flat)
+    assert int(st.radiance_rays[1]) > 0  # the floor reflects: secondary rays cross the instances too
+    want, _, _ = oracle.render(world, cam, 5, real_bits, threads=THREADS)
+    frac = u8_mismatch(oracle, img_inst, want)
+    print(f"teapot field {w}x{h} f{real_bits}: {frac:.3%} of the pixels differ by more than 1/255")
+    assert frac <= (0.002 if real_bits == 64 else 0.01)
+
+
+def test_sixteen_teapot_high_instances_at_full_size(oracle):
+    """16 copies of teapot-high.obj (101 120 triangles) under 16 group transformations at 1920x1080, f64: sampled
+    nearest hits and pixels against the oracle, and the cost per ray beside one teapot's and beside the same
+    scene with every triangle as a world-space leaf."""
+    import torch
+    from raytracer_amd import dist as rd
+    w, h = 1920, 1080
+    world, cam = scenes.teapot_field(w, h, "teapot-high.obj", 4)
+    one, cam_one = scenes.teapot_field(w, h, "teapot-high.obj", 1)
+    dev = Device.get(0, 64)
+
+    def timed(scene, camera):
+        out = torch.empty((h, w, 3), dtype=torch.float32, device="cuda")
+        st = Stats()
+        best = 1e30
+        for _ in range(4):
+            rd.render_canvas(scene, camera, 5, out.view(-1), st)
+            best = min(best, float(st.frame_ms))
+        return out, best, int(st.total_radiance) + int(st.total_shadow)
+
+    try:
+        _instancing(True)
+        scene = dev.upload(world)
+        info = scene.info()
+        assert info["bounded"] == 16, info
+        full, ms_inst, rays_inst = timed(scene, cam)
+        pxy, rays = camera_sample_rays(oracle, cam, 60000, 43)
+        more = scattered_rays(40000, 44, (-110, 0.2, -110), (110, 30, 110))
+        bad, n, ties, hits = compare_hits(oracle, world, scene, np.concatenate([rays, more]), 64)
+        print(f"16 x teapot-high: {bad} of {n} sampled rays outside the bar, {ties} ties excluded, {hits} hits")
+        assert bad == 0 and hits > 30000
+        scene.close()
+        scene = dev.upload(one)
+        _, ms_one, rays_one = timed(scene, cam_one)
+        scene.close()
+        _instancing(False)
+        scene = dev.upload(world)
+        flat, ms_flat, rays_flat = timed(scene, cam)
+        scene.close()
+    finally:
+        _instancing(True)
+    assert torch.equal(full, flat) and rays_flat == rays_inst
+    per_inst, per_one, per_flat = ms_inst / rays_inst, ms_one / rays_one, ms_flat / rays_flat
+    print(f"16 x teapot-high 1920x1080 f64: instanced {ms_inst:.3f} ms / {rays_inst} rays, one teapot {ms_one:.3f} ms / {rays_one} rays, "
+          f"world-space leaves {ms_flat:.3f} ms; per ray: instanced {per_inst / per_one:.2f}x one teapot, world-space {per_flat / per_one:.2f}x")
+    assert per_inst <= 1.5 * per_one
+    sel = slice(0, 500)
+    want = oracle.color_at(world, rays[sel], 5, 64, threads=THREADS)
+    got = full[torch.from_numpy(pxy[sel, 1]).cuda(), torch.from_numpy(pxy[sel, 0]).cuda()].cpu().numpy()
+    frac = u8_mismatch(oracle, got, want)
+    print(f"16 x teapot-high 1920x1080: {frac:.3%} of 500 sampled pixels differ by more than 1/255")
+    assert frac <= 0.005

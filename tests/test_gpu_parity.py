@@ -330,7 +330,8 @@ def test_every_launch_plan_renders_the_same_image(env, real_bits):
                 os.environ[k] = v
     try:
         for build in (lambda: scenes.glass(200, 150), lambda: scenes.north_star(160, 90, mesh="teapot-low.obj"),
-                      lambda: scenes.stress(128, 72, n_top=2, n_mid=6, n_leaf=25, extent=40.0)):
+                      lambda: scenes.stress(128, 72, n_top=2, n_mid=6, n_leaf=25, extent=40.0),
+                      lambda: scenes.teapot_field(160, 90, "teapot-low.obj", 3)):  # instanced meshes: two-level walks in every plan
             world, cam = build()
             # truncated cones are tested by every ray here: with cones inside the BVH the reference's hits beyond a
             # cone's extent are found or not depending on the order of the traversal, which differs between plans

@@ -597,6 +597,31 @@ def test_scene_check_rejects_what_the_reference_panics_on():
     assert lib.rt355_scene_check(singular.descs(), 1, 48, 0, out) == -1
 
 
+@pytest.mark.parametrize("real_bits", [32, 64])
+def test_group_transformed_meshes_become_instances(real_bits, monkeypatch):
+    """Runs of triangles that share one group transformation (src/group.rs:130-168) are built as instances: one
+    entry each in the top-level tree, an object-space tree per mesh below.  rt355_scene_check walks both levels:
+    every triangle reachable exactly once, every box encloses what lies below it."""
+    world, _ = scenes.teapot_field(64, 36, "teapot-low.obj", 3, through_groups=True)
+    assert world.n_shapes() == 1 + 1 + 9 * (1 + 240)  # floor, root group, per copy its group and its triangles
+    rc, info = _check(world, real_bits)
+    assert rc == 0, _abi.lib().rt355_last_error()
+    assert info["bounded"] == 9 and info["unbounded"] == 1  # nine instances; the floor plane beside the tree
+    assert info["stack"] <= 62
+    nodes_instanced = info["nodes"]
+    # meshes below the size that pays for a tree of their own stay world-space leaves; so does everything
+    # with the feature switched off
+    monkeypatch.setenv("RT355_INSTANCE_MIN", "100000")
+    rc, info = _check(world, real_bits)
+    assert rc == 0 and info["bounded"] == 9 * 240 and info["unbounded"] == 1
+    assert info["nodes"] != nodes_instanced
+    monkeypatch.delenv("RT355_INSTANCE_MIN")
+    # an identity group leaves its triangles as plain world-space triangles: nothing to instance
+    plain, _ = scenes.teapot_low(64, 36)
+    rc, info = _check(plain, real_bits)
+    assert rc == 0 and info["bounded"] == plain.n_shapes()
+
+
 # ------------------------------------------------------------------------------------------------
 # C++ host mirror (include/rt355.hpp): its own test program, built by __graft_entry__.build()
 # ------------------------------------------------------------------------------------------------
