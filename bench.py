@@ -74,6 +74,10 @@ def main():
     ap.add_argument("--real", type=int, default=64, choices=[32, 64])
     ap.add_argument("--in-flight", type=int, default=3, help="frames kept in flight on each GPU (1: every step waits for its own frame)")
     ap.add_argument("--batch", type=int, default=0, help="frames per launch chain (0: max(8, number of GPUs), bounded by 16 GB of ray pool per chain)")
+    ap.add_argument("--canvas", default="auto", choices=["auto", "float", "u8"],
+                    help="what a step leaves on rank 0: the float canvas (Canvas.pixels) or its Color::to_u8 bytes, the body of the PPM the "
+                         "reference writes per frame.  auto: float on one GPU (rendered in place, nothing to gather), u8 on several (the tiles "
+                         "are converted where they are rendered and a quarter of the bytes cross xGMI)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the 3840x2160 figure that is reported beside the headline")
     ap.add_argument("--rehearse", action="store_true",
@@ -105,7 +109,8 @@ def main():
     # per primary ray, 116 B each in f64) stays below 16 GB
     pool_bytes_per_frame = rd.tiles_per_rank(w, h, world_size) * rd.TILE * rd.TILE * 8 * (116 if args.real == 64 else 64)
     batch = args.batch if args.batch > 0 else max(1, min(max(8, world_size), int(16e9 // pool_bytes_per_frame)))
-    loop = rd.FrameLoop(scene, dev, w, h, rank, world_size, args.depth, in_flight=args.in_flight, batch=batch)
+    as_u8 = args.canvas == "u8" or (args.canvas == "auto" and world_size > 1)
+    loop = rd.FrameLoop(scene, dev, w, h, rank, world_size, args.depth, in_flight=args.in_flight, batch=batch, as_u8=as_u8)
     local = torch.empty(rd.tiles_per_rank(w, h, world_size) * rd.TILE * rd.TILE * 3, dtype=torch.float32, device="cuda")
     st = Stats()
     # every frame has a camera of its own: a slow orbit around the scene (0.001 rad per frame, 64 frames, then again),
@@ -178,8 +183,9 @@ def main():
                        "shapes": world.n_shapes(), "rays_per_frame": rays_frame, "primary_rays_per_frame": primary_frame,
                        "primary_mrays_per_s": round(primary_frame / (ms * 1e-3) / 1e6, 3),
                        "parallelism": f"tile{world_size}",
-                       # bytes that arrive at rank 0 per frame in the canvas gather (float tiles; a quarter of it with as_u8)
-                       "gather_bytes_per_frame": (world_size - 1) * rd.tiles_per_rank(w, h, world_size) * rd.TILE * rd.TILE * 3 * 4, "chains_in_flight": loop.K, "frames_per_chain": loop.B, "single_frame_ms": round(single_ms, 4),
+                       "canvas": "u8" if as_u8 else "float",
+                       # bytes that arrive at rank 0 per frame in the canvas gather
+                       "gather_bytes_per_frame": (world_size - 1) * rd.tiles_per_rank(w, h, world_size) * rd.TILE * rd.TILE * 3 * (1 if as_u8 else 4), "chains_in_flight": loop.K, "frames_per_chain": loop.B, "single_frame_ms": round(single_ms, 4),
                        "bvh": scene.info()},
         }
         # --- roofline of the dominant kernel: separate frames, never inside the timed region above ----

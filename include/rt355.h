@@ -307,6 +307,20 @@ int rt355_to_u8(rt355_ctx*, const float* rgb, size_t n, uint8_t* out);
  * of the bytes to copy out.  Synchronous with respect to the host. */
 int rt355_to_u8_device(rt355_ctx*, const float* rgb_dev, size_t n, uint8_t* out_dev);
 
+/* Ordering against the caller's own HIP streams, for frame loops that must not stall the host between a
+ * collective and the launch that consumes it.  No counterpart in the reference (it has no device).
+ * rt355_ctx_wait_stream: whatever the context launches from now on starts after the work queued on `hip_stream`
+ * (a hipStream_t; NULL is the legacy default stream) so far -- e.g. the gather that fills the buffer rt355_untile
+ * reads.  rt355_stream_wait_ctx: the other direction, work queued on `hip_stream` after the call starts once
+ * everything the context has launched is done -- e.g. the consumer of an un-tiled canvas, or the send of converted
+ * tiles.  Neither blocks the host.
+ * rt355_ctx_set_async(ctx, 1): rt355_untile*, rt355_to_u8_device stop waiting for their own launch (they only queue
+ * it); the caller orders with the two calls above or ends with rt355_ctx_sync.  0 (the default) restores the wait. */
+int rt355_ctx_wait_stream(rt355_ctx*, void* hip_stream);
+int rt355_stream_wait_ctx(rt355_ctx*, void* hip_stream);
+int rt355_ctx_set_async(rt355_ctx*, int on);
+int rt355_ctx_sync(rt355_ctx*);
+
 /* Host only, needs no GPU: builds the scene tables and the BVH exactly as rt355_scene_upload does
  * (real_bits picks the box padding) and checks their structure: every bounded shape in exactly one
  * leaf, every child box enclosing what lies beneath it, the traversal stack bound.  out[0]=nodes,

@@ -125,6 +125,10 @@ SYMBOLS = [
     ("rt355_is_shadowed", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("rt355_to_u8", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("rt355_to_u8_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("rt355_ctx_wait_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("rt355_stream_wait_ctx", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("rt355_ctx_set_async", C.c_int, [C.c_void_p, C.c_int]),
+    ("rt355_ctx_sync", C.c_int, [C.c_void_p]),
     ("rt355_scene_check", C.c_int, [C.POINTER(ShapeDesc), C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
     ("rt355_flop_table", None, [C.POINTER(C.c_double)]),
 ]

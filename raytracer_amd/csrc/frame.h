@@ -106,6 +106,8 @@ struct rt355_ctx {
   std::chrono::steady_clock::time_point pending_t0;
   double pending_primary_flops = 0;
   int n_cu = 256;
+  hipEvent_t ev_order = nullptr;  // rt355_ctx_wait_stream / rt355_stream_wait_ctx
+  bool async_helpers = false;     // rt355_untile* / rt355_to_u8_device only queue their launch
 };
 
 struct rt355_scene {

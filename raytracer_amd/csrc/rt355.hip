@@ -464,7 +464,7 @@ int untile_impl(rt355_ctx* c, const rt355_camera_desc* cam, int n_ranks, int n_f
   hipLaunchKernelGGL((k_untile<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, gathered_dev, out_dev, w, h, tiles_x,
                      tiles_x * tiles_y, n_ranks, (long long)tiles_per_rank_of(w, h, n_ranks), n_frames);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (!c->async_helpers) HIP_TRY(hipStreamSynchronize(c->stream));
   return RT355_OK;
 }
 
@@ -546,6 +546,7 @@ void rt355_ctx_destroy(rt355_ctx* c) {
   for (hipEvent_t e : c->ev_traced)
     if (e) (void)hipEventDestroy(e);
   if (c->ev_side_done) (void)hipEventDestroy(c->ev_side_done);
+  if (c->ev_order) (void)hipEventDestroy(c->ev_order);
   if (c->side) (void)hipStreamDestroy(c->side);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->ctl_host) (void)hipHostFree(c->ctl_host);
@@ -847,6 +848,40 @@ int rt355_to_u8_device(rt355_ctx* c, const float* rgb_dev, size_t n, uint8_t* ou
   if (n == 0) return RT355_OK;
   hipLaunchKernelGGL(k_to_u8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, rgb_dev, n, out_dev);
   HIP_TRY(hipGetLastError());
+  if (!c->async_helpers) HIP_TRY(hipStreamSynchronize(c->stream));
+  return RT355_OK;
+}
+
+int rt355_ctx_wait_stream(rt355_ctx* c, void* hip_stream) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!c->ev_order) HIP_TRY(hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(c->ev_order, (hipStream_t)hip_stream));
+  HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_order, 0));
+  return RT355_OK;
+}
+
+int rt355_stream_wait_ctx(rt355_ctx* c, void* hip_stream) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (c->pending) return set_err(RT355_EINVAL, "a frame is in flight on this context: end it with rt355_frame_end first");
+  if (!c->ev_order) HIP_TRY(hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming));
+  // every entry point leaves the side stream joined to the main one, so the main stream's tail covers both
+  HIP_TRY(hipEventRecord(c->ev_order, c->stream));
+  HIP_TRY(hipStreamWaitEvent((hipStream_t)hip_stream, c->ev_order, 0));
+  return RT355_OK;
+}
+
+int rt355_ctx_set_async(rt355_ctx* c, int on) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  c->async_helpers = on != 0;
+  return RT355_OK;
+}
+
+int rt355_ctx_sync(rt355_ctx* c) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));
   return RT355_OK;
 }

@@ -115,7 +115,9 @@ class FrameLoop:
     communication stream and returns, while the library renders on streams of its own: a rank other than 0 that
     rendered later frames into the same buffer could overwrite tiles that are still being sent.  Each slot
     therefore remembers an event recorded behind its last send and does not render before that event has
-    passed (in steady state it passed long ago).  Rank 0 synchronises with the gather before it un-tiles.
+    passed (in steady state it passed long ago).  On rank 0 the un-tiling is ordered behind the gather, and the
+    caller's stream behind the un-tiling, by events: the canvases a step hands back are valid for work queued on
+    torch's current stream (or after torch.cuda.synchronize()), and the host waits only in rt355_frame_end.
 
     `render(camera, out_tensor, stats)` writes this rank's tiles of one frame into the tensor it is given; the
     default calls the library (CUDA tensors); tests pass their own to run the same loop on CPU tensors over
@@ -214,9 +216,26 @@ class FrameLoop:
             self.ready.extend(self.canvases[self.where[k]][f] for f in range(nf))
             return
         tiles, send = self.tiles[k][: nf * n], self.send[k][: nf * n]
+        # Between here and the canvases the host waits for nothing: the conversion and the un-tiling are only queued
+        # on the library's stream, the collective on torch's, and the two are ordered by events
+        # (rt355_stream_wait_ctx / rt355_ctx_wait_stream).
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream) if self.cuda else None
+        if self.cuda:
+            _abi.check(ctx.lib.rt355_ctx_set_async(ctx.handle, 1))
+        try:
+            self._gather_and_untile(k, ctx, cameras, tiles, send, stream)
+        finally:
+            if self.cuda:
+                _abi.check(ctx.lib.rt355_ctx_set_async(ctx.handle, 0))
+
+    def _gather_and_untile(self, k, ctx, cameras, tiles, send, stream):
+        import torch
+        import torch.distributed as dist
+        nf, n = len(cameras), self.n
         if self.as_u8:
             if self.cuda:
                 _abi.check(ctx.lib.rt355_to_u8_device(ctx.handle, C.c_void_p(tiles.data_ptr()), tiles.numel(), C.c_void_p(send.data_ptr())))
+                _abi.check(ctx.lib.rt355_stream_wait_ctx(ctx.handle, stream))  # the send reads the converted tiles
             else:
                 from .host import Color
                 send.copy_(torch.from_numpy(Color.to_u8(tiles.numpy())))
@@ -235,9 +254,13 @@ class FrameLoop:
         canvases = self.canvases[0]
         if self.cuda:
             fn = ctx.lib.rt355_untile_batch_u8 if self.as_u8 else ctx.lib.rt355_untile_batch
-            torch.cuda.current_stream().synchronize()  # the gather has landed before the library's stream reads it
+            # the library's stream waits for the gather (and for whatever the caller still has queued on the canvases)
+            _abi.check(ctx.lib.rt355_ctx_wait_stream(ctx.handle, stream))
             cd = cameras[0].to_desc()
             _abi.check(fn(ctx.handle, C.byref(cd), self.world_size, nf, C.c_void_p(gathered.data_ptr()), C.c_void_p(canvases.data_ptr())))
+            # what the caller queues on torch's stream from here on (its use of the canvases, the next gather into the
+            # shared buffer) starts behind the un-tiling
+            _abi.check(ctx.lib.rt355_stream_wait_ctx(ctx.handle, stream))
         else:
             g = gathered.numpy()
             for f in range(nf):

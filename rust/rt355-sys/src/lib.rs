@@ -171,6 +171,10 @@ extern "C" {
                              out: *mut u8) -> c_int;
     pub fn rt355_to_u8(ctx: *mut rt355_ctx, rgb: *const f32, n: usize, out: *mut u8) -> c_int;
     pub fn rt355_to_u8_device(ctx: *mut rt355_ctx, rgb_dev: *const f32, n: usize, out_dev: *mut u8) -> c_int;
+    pub fn rt355_ctx_wait_stream(ctx: *mut rt355_ctx, hip_stream: *mut c_void) -> c_int;
+    pub fn rt355_stream_wait_ctx(ctx: *mut rt355_ctx, hip_stream: *mut c_void) -> c_int;
+    pub fn rt355_ctx_set_async(ctx: *mut rt355_ctx, on: c_int) -> c_int;
+    pub fn rt355_ctx_sync(ctx: *mut rt355_ctx) -> c_int;
     pub fn rt355_scene_check(shapes: *const rt355_shape_desc, n_shapes: usize, real_bits: c_int,
                              exact_cones: c_int, out: *mut u64) -> c_int;
     pub fn rt355_flop_table(out: *mut f64);
