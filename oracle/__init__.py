@@ -13,7 +13,8 @@ from raytracer_amd import _abi
 from raytracer_amd.host import shapes_to_descs
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liboracle.so")
+# RT355_ORACLE_LIB: another build of the same oracle (the sanitizer build of `make -C oracle asan`)
+LIB_PATH = os.environ.get("RT355_ORACLE_LIB") or os.path.join(HERE, "liboracle.so")
 STRICT_UV = 1
 
 
