@@ -539,6 +539,22 @@ def test_headline_frame_at_full_size(oracle):
     bad = (np.abs(oracle.to_u8(got).astype(int) - oracle.to_u8(want).astype(int)).max(axis=1) > 1).mean()
     print(f"headline frame: {bad:.3%} of 400 sampled pixels differ by more than 1/255")
     assert bad <= 0.01
+    # How much of this frame lies where the reference itself has no answer: a hit on a smooth triangle whose ray has
+    # another shape's intersection as xs[0] (the floor at a small negative t behind a reflected ray) makes the
+    # reference panic (src/intersection.rs:67-71); device and oracle take the hit's own u, v there.  Counted by the
+    # oracle's strict_uv switch over windows spread across the frame.
+    import oracle as o
+    size, pixels, panics, hits = 8, 0, 0, 0
+    for wy in range(60, h - size, 120):       # a regular grid of 8x8 windows: 9 rows x 12 columns
+        for wx in range(80, w - size, 160):
+            _, cnt, _ = oracle.render(world, cam, 5, 64, o.STRICT_UV, window=(wx, wx + size, wy, wy + size), threads=16)
+            pixels += size * size
+            panics += cnt["panics"]
+            hits += int(cnt["hits"].sum())
+    print(f"headline frame: {panics} of {pixels} sampled pixels ({panics / pixels:.1%}, about {panics / pixels * w * h:.0f} of the frame's {w * h}) "
+          f"carry a hit where the reference would panic (smooth triangle hit by a ray whose xs[0] is another shape); "
+          f"{hits} hits in the sampled pixels' ray trees")
+    assert 0 < panics < pixels
 
 
 @pytest.mark.parametrize("second_index", [1.0, 1.3])
