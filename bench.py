@@ -328,7 +328,7 @@ def source_hash():
     """Hash of the device sources: the committed PMC figures are only quoted for the kernels they were measured on."""
     import hashlib
     hsh = hashlib.sha256()
-    for name in ("kernels.h", "rt355.hip", "rt355_device.h", "scene_build.cpp"):
+    for name in ("kernels.h", "frame.h", "frame_inst.hip", "rt355.hip", "rt355_device.h", "scene_build.cpp"):
         with open(os.path.join(ROOT, "raytracer_amd", "csrc", name), "rb") as fh:
             hsh.update(fh.read())
     return hsh.hexdigest()[:16]

@@ -33,8 +33,6 @@ for i in sorted(rows):
         continue
     gen = seen[base]
     seen[base] += 1
-    if base == "k_combine":
-        continue  # generation numbering of the combine launches runs backwards; not needed here
     g = lambda k: r.get(k, 0.0)
     fp64 = 64.0 * (g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64") + g("SQ_INSTS_VALU_TRANS_F64") + 2.0 * g("SQ_INSTS_VALU_FMA_F64"))
     e = {"kernel": r["_name"], "fetch_kib": g("FETCH_SIZE"), "write_kib": g("WRITE_SIZE"),
@@ -48,12 +46,17 @@ for i in sorted(rows):
         e["l2_hit_rate"] = round(g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")), 4)
     e["waves"] = int(g("SQ_WAVES"))
     e["valu_instructions"] = int(g("SQ_INSTS_VALU"))
-    launches[f"{base} generation {gen}"] = e
+    # the combine launches run from the deepest folded generation back to generation 0: keyed by their order
+    launches[f"{base} launch {gen}" if base == "k_combine" else f"{base} generation {gen}"] = e
 import bench
 frames = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 doc = {"source": f"rocprofv3 --pmc, one pass per counter set (scripts/pmc.sh), north_star 1920x1080 depth 5 f64, 1 GPU, one launch chain of {frames} frames; per launch",
        "frames_per_chain": frames,
        "correction": "hbm_bytes = (FETCH_SIZE x 2 + WRITE_SIZE) KiB: gfx950 counts wide reads at half size",
-       "source_hash": bench.source_hash(), "launches": launches}
+       "source_hash": bench.source_hash(),
+       "per_frame": {"valu_instructions": int(sum(e["valu_instructions"] for e in launches.values()) / frames),
+                     "hbm_bytes": int(sum(e["hbm_bytes"] for e in launches.values()) / frames),
+                     "fp64_flops_upper_bound": sum(e["fp64_flops_upper_bound"] for e in launches.values()) / frames},
+       "launches": launches}
 json.dump(doc, open(out_path, "w"), indent=1)
 print("wrote", out_path, len(launches), "launches")
