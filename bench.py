@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--real", type=int, default=64, choices=[32, 64])
     ap.add_argument("--in-flight", type=int, default=3, help="frames kept in flight on each GPU (1: every step waits for its own frame)")
-    ap.add_argument("--batch", type=int, default=0, help="frames per launch chain (0: max(8, number of GPUs), bounded by 16 GB of ray pool per chain)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per launch chain (0: max(16, number of GPUs), bounded by 32 GB of ray pool per chain)")
     ap.add_argument("--canvas", default="auto", choices=["auto", "float", "u8"],
                     help="what a step leaves on rank 0: the float canvas (Canvas.pixels) or its Color::to_u8 bytes, the body of the PPM the "
                          "reference writes per frame.  auto: float on one GPU (rendered in place, nothing to gather), u8 on several (the tiles "
@@ -106,9 +106,12 @@ def main():
     # completes the one begun K steps earlier; the flush before each fence completes the rest, so exactly
     # `steps` whole frames (render + gather + un-tile) lie between the two fences.
     # frames per chain: at least a whole frame's worth of tiles per rank, as long as one chain's ray pool (8 ray slots
-    # per primary ray, 116 B each in f64) stays below 16 GB
+    # per primary ray, 116 B each in f64) stays below 32 GB: three chains in flight then hold a third of the 288 GB of HBM.
+    # Measured on the headline frame (ms per step, chains in flight x frames per chain): 3 x 8 0.502, 3 x 12 0.485,
+    # 3 x 16 0.469, 2 x 24 0.474, 2 x 32 0.478 -- the deeper generations of a chain hold few rays, and every
+    # launch ends on its slowest wave.
     pool_bytes_per_frame = rd.tiles_per_rank(w, h, world_size) * rd.TILE * rd.TILE * 8 * (116 if args.real == 64 else 64)
-    batch = args.batch if args.batch > 0 else max(1, min(max(8, world_size), int(16e9 // pool_bytes_per_frame)))
+    batch = args.batch if args.batch > 0 else max(1, min(max(16, world_size), int(32e9 // pool_bytes_per_frame)))
     as_u8 = args.canvas == "u8" or (args.canvas == "auto" and world_size > 1)
     loop = rd.FrameLoop(scene, dev, w, h, rank, world_size, args.depth, in_flight=args.in_flight, batch=batch, as_u8=as_u8)
     local = torch.empty(rd.tiles_per_rank(w, h, world_size) * rd.TILE * rd.TILE * 3, dtype=torch.float32, device="cuda")

@@ -584,22 +584,44 @@ RT_FN bool walk_packet(const DevScene<R>& sc, int root, V3<R> o, V3<R> d, bool l
         const float b = (float)vis.tmax();
         thi = fminf(b + fabsf(b) * 1.1920929e-7f, 3.4028235e38f);
       }
-      // A child is entered when any live lane may touch it.  Order: by the entry parameter of the first
-      // lane that touches the child (a scalar, so the sort runs on the scalar unit).
-      uint32_t key[BVH_WIDTH];
+      // A child is entered when any live lane may touch it.
+      unsigned long long m[BVH_WIDTH];
+      float tn[BVH_WIDTH];
       int n_valid = 0;
 #pragma unroll
       for (int k = 0; k < BVH_WIDTH; ++k) {
-        float tn;
         // the compare's own lane mask, narrowed to the live lanes on the scalar unit
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(slab_test_p(sr, B[k][0], B[k][1], B[k][2], tlo, thi, tn)) & live_mask;
+        m[k] = __builtin_amdgcn_ballot_w64(slab_test_p(sr, B[k][0], B[k][1], B[k][2], tlo, thi, tn[k])) & live_mask;
         if constexpr (MODE & M_COUNT) n_valid += ch[k] != -1;
+      }
+#ifndef RT355_EXP_NO_SINGLE_CHILD
+      // Deep in the tree a packet mostly touches one child of a node, or none: those steps need no order and no stack
+      // traffic, and leave before the keys are even formed.
+      {
+        const int touched = (m[0] != 0ull) + (m[1] != 0ull) + (m[2] != 0ull) + (m[3] != 0ull);
+        if (touched <= 1) {
+          if constexpr (MODE & M_COUNT) wk.box += live ? n_valid : 0;
+          if (touched == 1) {
+            cur = m[0] ? ch[0] : m[1] ? ch[1] : m[2] ? ch[2] : ch[3];
+            continue;
+          }
+          if (sp == sp0) return live;
+          cur = __builtin_amdgcn_readlane(stackv, --sp);
+          continue;
+        }
+      }
+#endif
+      // Order: by the entry parameter of the first lane that touches the child (a scalar, so the sort runs on the
+      // scalar unit).
+      uint32_t key[BVH_WIDTH];
+#pragma unroll
+      for (int k = 0; k < BVH_WIDTH; ++k) {
         // entry parameter of the first lane that touches the child; with no such lane the scalar bit search yields -1,
         // the lane read is then any lane's and the key is discarded.  Negative entries (visitors whose interval starts
         // below zero) order as zero.
-        const int lane = __builtin_ffsll((long long)m) - 1;
-        const int bits = __builtin_amdgcn_readlane((int)__float_as_uint(tn), lane);
-        key[k] = m ? (uint32_t)(bits < 0 ? 0 : bits) : 0xFFFFFFFFu;
+        const int lane = __builtin_ffsll((long long)m[k]) - 1;
+        const int bits = __builtin_amdgcn_readlane((int)__float_as_uint(tn[k]), lane);
+        key[k] = m[k] ? (uint32_t)(bits < 0 ? 0 : bits) : 0xFFFFFFFFu;
       }
       if constexpr (MODE & M_COUNT) wk.box += live ? n_valid : 0;
       auto order = [](uint32_t& ka, int& ca, uint32_t& kb, int& cb) {

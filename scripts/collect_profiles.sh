@@ -3,7 +3,7 @@
 tag=$1; r=$2
 src=gpurun_out/prof_$tag
 cd "$(dirname "$0")/.."
-python3 scripts/make_counters.py $src/pmc $src/counters.json 8 || exit 1
+python3 scripts/make_counters.py $src/pmc $src/counters.json 16 || exit 1
 cp $src/bench.json profiles/${r}_bench_under_rocprof.json
 cp $src/bench_k3.json profiles/${r}_bench_default_run_under_rocprof.json
 cp $src/kernel_stats.csv profiles/${r}_kernel_stats.csv

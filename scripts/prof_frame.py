@@ -14,7 +14,7 @@ ap.add_argument("--scene", default="north_star")
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--frames", type=int, default=3, help="launch chains to run")
-ap.add_argument("--batch", type=int, default=8, help="frames per launch chain (the bench default at one GPU)")
+ap.add_argument("--batch", type=int, default=16, help="frames per launch chain (the bench default at one GPU)")
 ap.add_argument("--real", type=int, default=64)
 ap.add_argument("--keep", default="", help="diagnostic: keep only these shapes of the scene: floor, sphere, mesh (comma list); 'matte' also makes every material non-reflective and opaque")
 a = ap.parse_args()
