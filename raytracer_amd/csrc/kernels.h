@@ -53,6 +53,21 @@ template <class R> RT_FN V3<R> normalize(V3<R> a) {
 template <class R> RT_FN V3<R> reflect(V3<R> v, V3<R> n) {  // src/tuple.rs:38-40
   return v - n * R(2) * dot(v, n);
 }
+// A record read in full, 16 bytes per request, all requests issued before the first value is used.  The empty asm pins
+// the values here: without it the compiler moves each field's load down to the block that uses it.
+template <class T>
+RT_FN T load_whole(const T* p) {
+  static_assert(sizeof(T) % 8 == 0, "records are read in 8-byte words");
+  constexpr int N = sizeof(T) / 8;
+  union U { T t; unsigned long long w[N]; RT_FN U() {} } u;
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+#pragma unroll
+  for (int k = 0; k < N; ++k) u.w[k] = q[k];
+#pragma unroll
+  for (int k = 0; k < N; ++k) asm volatile("" : "+v"(u.w[k]));
+  return u.t;
+}
+
 template <class R> RT_FN V3<R> ld3(const R* p) { return {p[0], p[1], p[2]}; }
 template <class R> RT_FN void st3(R* p, V3<R> v) { p[0] = v.x, p[1] = v.y, p[2] = v.z; }
 
@@ -511,6 +526,7 @@ RT_FN DevTri load_tri_uniform(const DevScene<R>& sc, int p) {
   return T;
 }
 
+constexpr int PARK_INTS = 6 * BLOCK * 2;  // six values of R (at most 8 bytes) per lane
 constexpr int PACKET_LEAF_GROUP = 2;  // triangle records of a leaf the packet traversal holds at a time
 
 // The slab constants of a packet's ray.  Per axis the two planes of a box give a = fma(lo, i, ca) and
@@ -1146,7 +1162,7 @@ RT_FN void trace_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* 
 // child bound of its own 64 rays for k_scan (entry i / 64 of blk_hits / blk_children): no wave waits for another.
 template <class R, int MODE, bool PACKET, bool LAST>
 __global__ void __launch_bounds__(BLOCK, PACKET ? (LAST ? RT355_WPS_PACKET_LAST : RT355_WPS_PACKET) : RT355_WPS_LANE) k_trace(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int remaining, int launch, DevCamera<R> cam, int primary) {
-  __shared__ int lds_stack[PACKET ? 1 : LDS_STACK * BLOCK];
+  __shared__ int lds_stack[PACKET ? PARK_INTS : LDS_STACK * BLOCK];  // packets: shade_surface parks two vectors per lane here
   int* lds = lds_stack + (PACKET ? 0 : threadIdx.x);
   uint32_t start, count;
   gen_range(ctl, gen, pool.capacity, start, count);
@@ -1380,22 +1396,30 @@ RT_FN V3<R> normal_at(const DevScene<R>& sc, int p, int flags, V3<R> point, R u,
   }
 }
 
+// x % 2.0 (Rust's float remainder = fmod, src/pattern.rs:100-117) without the library's general remainder loop, which
+// takes over a hundred instructions in double.  x / 2 is exact in binary floating point, so is its truncation, so is
+// twice that, and the difference is exact because it is smaller than x and on x's grid: x - 2 * trunc(x / 2) IS
+// fmod(x, 2) for every finite x, up to the sign of a zero result (the callers compare with zero or take the floor of a
+// non-negative value); an infinite or NaN x gives NaN either way.
+template <class R>
+RT_FN R fmod2(R x) { return x - R(2) * trunc(x * R(0.5)); }
+
 // Pattern::pattern_at (src/pattern.rs:93-121): evaluated on the world-space point, no transformation.
 template <class R>
 RT_FN V3<R> pattern_at(const DevMaterial<R>& m, V3<R> p) {
   const V3<R> c1 = ld3(m.c1), c2 = ld3(m.c2);
   switch (m.pattern_kind) {
     case RT355_PATTERN_STRIPE:
-      return fmod(floor(p.x), R(2)) == R(0) ? c1 : c2;
+      return fmod2(floor(p.x)) == R(0) ? c1 : c2;
     case RT355_PATTERN_GRADIENT: {
       const R f = p.x - floor(p.x);
       const V3<R> dd = c2 - c1;
       return {c1.x + f * dd.x, c1.y + f * dd.y, c1.z + f * dd.z};
     }
     case RT355_PATTERN_RING:
-      return floor(fmod(sqrt(p.x * p.x + p.z * p.z), R(2))) == R(0) ? c1 : c2;
+      return floor(fmod2(sqrt(p.x * p.x + p.z * p.z))) == R(0) ? c1 : c2;
     case RT355_PATTERN_CHECKER:
-      return fmod(floor(p.x) + floor(p.y) + floor(p.z), R(2)) == R(0) ? c1 : c2;
+      return fmod2(floor(p.x) + floor(p.y) + floor(p.z)) == R(0) ? c1 : c2;
     case RT355_PATTERN_TEST:
       return p;
     default:
@@ -1529,7 +1553,7 @@ RT_FN void spawn_reflection(const RayPool<R>& pool, uint32_t r, bool slot_r, boo
   }
   if (slot_r || slot_t) {
     pool.child[2ull * r] = child_r;
-    if (!slot_t) pool.child[2ull * r + 1] = -1, pool.mixr[r] = R(-1);
+    if (!slot_t) pool.child[2ull * r + 1] = -1;  // the Schlick weight is read only for prims flagged PF_SCHLICK, which are transparent
   }
 }
 
@@ -1549,9 +1573,22 @@ RT_FN void shade_surface(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t
   R limit;
   light_ray(sc, pc.over_point, ldir, limit);
   AnyVis<R, MODE> av(sc, pc.over_point, ldir, limit, wk);
+  V3<R> eyev = pc.eyev, normalv = pc.normalv;
 #ifndef RT355_EXP_NO_SHADOW_TRAV
   if constexpr (PACKET) {
-    traverse_packet<R, MODE>(sc, pc.over_point, ldir, valid, av, wk, lds);
+    // The packet kernels run at the register budget of four waves per SIMD and the traversal fills it: what only
+    // the lighting needs waits in LDS meanwhile (one column per lane, so no bank conflicts and no barrier) instead
+    // of being spilled to scratch memory by the compiler.
+    R* park = reinterpret_cast<R*>(lds) + (threadIdx.x & (BLOCK - 1));
+#ifndef RT355_EXP_NO_PARK
+    park[0 * BLOCK] = eyev.x, park[1 * BLOCK] = eyev.y, park[2 * BLOCK] = eyev.z;
+    park[3 * BLOCK] = normalv.x, park[4 * BLOCK] = normalv.y, park[5 * BLOCK] = normalv.z;
+#endif
+    traverse_packet<R, MODE>(sc, pc.over_point, ldir, valid, av, wk, nullptr);
+#ifndef RT355_EXP_NO_PARK
+    eyev = {park[0 * BLOCK], park[1 * BLOCK], park[2 * BLOCK]};
+    normalv = {park[3 * BLOCK], park[4 * BLOCK], park[5 * BLOCK]};
+#endif
   } else {
     if (valid) traverse<R, MODE>(sc, pc.over_point, ldir, av, wk, lds);
   }
@@ -1560,8 +1597,10 @@ RT_FN void shade_surface(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t
 #ifdef RT355_EXP_NO_LIGHT
     st3(pool.color + 3ull * r, av.found ? pc.over_point : ldir);
 #else
-    const DevMaterial<R>& m = sc.materials[flags >> PF_MAT_SHIFT];
-    st3(pool.color + 3ull * r, lighting(sc, m, pc.over_point, pc.eyev, pc.normalv, av.found));
+    // the whole record at once: read field by field as lighting() comes to them, every field is a memory round trip
+    // of its own behind the branch that needs it (pattern kind, then its colours, then ambient, diffuse, shininess ...)
+    const DevMaterial<R> m = load_whole(&sc.materials[flags >> PF_MAT_SHIFT]);
+    st3(pool.color + 3ull * r, lighting(sc, m, pc.over_point, eyev, normalv, av.found));
 #endif
   }
 }
@@ -1672,7 +1711,7 @@ template <class R, int MODE, bool PACKET, bool SPAWN>
 __global__ void __launch_bounds__(BLOCK, PACKET ? RT355_WPS_PACKET : RT355_WPS_LANE) k_shadow(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int launch) {
   uint32_t start, gcount;
   gen_range(ctl, gen, pool.capacity, start, gcount);
-  __shared__ int lds_stack[PACKET ? 1 : LDS_STACK * BLOCK];  // the packet traversal keeps its stack in a register
+  __shared__ int lds_stack[PACKET ? PARK_INTS : LDS_STACK * BLOCK];  // packets: shade_surface parks two vectors per lane here
   int* lds = lds_stack + (PACKET ? 0 : threadIdx.x);
   Work wk;
   // the hit record of the next trip is requested before this trip's work starts: its latency (a round trip to HBM)
@@ -1687,12 +1726,13 @@ __global__ void __launch_bounds__(BLOCK, PACKET ? RT355_WPS_PACKET : RT355_WPS_L
     const HitRec hit = next;
     if (rbase + stride < gcount) next = load_hit(pool, start + (i + stride < gcount ? i + stride : 0u));
     const bool valid = i < gcount && hit.prim >= 0;
-    if (__ballot(valid) == 0ull) continue;  // wave-uniform
-    HitRay<R> h{};
-    if (valid) h = load_hit_ray(pool, r, hit.flags);
-    SpawnAt at{ctl, start + gcount, 0u};
-    if constexpr (SPAWN) at.base = child_base(pool.blk_base, pool.blk_top, __builtin_amdgcn_readfirstlane(i) / GROUP);
-    shade_surface<R, MODE, PACKET, SPAWN>(sc, pool, r, valid, valid ? hit.prim : 0, hit.flags, h, lds, wk, &at);
+    if (__ballot(valid) != 0ull) {  // wave-uniform
+      HitRay<R> h{};
+      if (valid) h = load_hit_ray(pool, r, hit.flags);
+      SpawnAt at{ctl, start + gcount, 0u};
+      if constexpr (SPAWN) at.base = child_base(pool.blk_base, pool.blk_top, __builtin_amdgcn_readfirstlane(i) / GROUP);
+      shade_surface<R, MODE, PACKET, SPAWN>(sc, pool, r, valid, valid ? hit.prim : 0, hit.flags, h, lds, wk, &at);
+    }
   }
   flush_work<(MODE & M_COUNT) != 0>(ctl, launch, wk);
 }
@@ -1860,11 +1900,12 @@ RT_FN void spawn_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* 
     }
   }
   if constexpr (ONLY_T) {
-    if (slot_t) pool.child[2ull * r + 1] = child_t, pool.mixr[r] = rs;
+    if (slot_t) pool.child[2ull * r + 1] = child_t;
+    if (slot_t && (info.flags & PF_SCHLICK)) pool.mixr[r] = rs;
   } else if (slot_r || slot_t) {  // k_combine looks at these only for hits on reflective / transparent shapes
     pool.child[2ull * r] = child_r;
     pool.child[2ull * r + 1] = child_t;
-    pool.mixr[r] = rs;
+    if (info.flags & PF_SCHLICK) pool.mixr[r] = rs;  // -1 (plain sum) for every other prim: k_combine does not read it then
   }
 }
 
@@ -1926,7 +1967,10 @@ RT_FN V3<R> ray_colour(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t r
   const V3<R> surface = ld3(pool.color + 3ull * r);  // left there by k_shadow
   int32_t cr = -1, ct = -1;
   R rs = R(-1);
-  if (has_children && (info.flags & (PF_REFLECTIVE | PF_TRANSPARENT))) cr = pool.child[2ull * r], ct = pool.child[2ull * r + 1], rs = pool.mixr[r];
+  if (has_children && (info.flags & (PF_REFLECTIVE | PF_TRANSPARENT))) {
+    cr = pool.child[2ull * r], ct = pool.child[2ull * r + 1];
+    if (info.flags & PF_SCHLICK) rs = pool.mixr[r];  // written for these prims only
+  }
   V3<R> refl = {R(0), R(0), R(0)}, refr = {R(0), R(0), R(0)};
   if constexpr (LEVELS > 0) {
     // every generation walked here lies above the deepest one, so its hits may have children

@@ -16,6 +16,7 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--frames", type=int, default=3, help="launch chains to run")
 ap.add_argument("--batch", type=int, default=16, help="frames per launch chain (the bench default at one GPU)")
 ap.add_argument("--real", type=int, default=64)
+ap.add_argument("--single", action="store_true", help="one frame per call, begun and waited for (rt355_render_tiles): the plan of a frame rendered alone")
 ap.add_argument("--keep", default="", help="diagnostic: keep only these shapes of the scene: floor, sphere, mesh (comma list); 'matte' also makes every material non-reflective and opaque")
 a = ap.parse_args()
 world, cam = scenes.CONFIGS[a.scene](a.width, a.height)
@@ -34,6 +35,9 @@ dev = Device.get(0, a.real)
 scene = dev.upload(world)
 out = torch.empty(a.batch * rd.tiles_per_rank(a.width, a.height, 1) * 1024 * 3, dtype=torch.float32, device="cuda")
 for _ in range(a.frames):
-    rd.render_tiles_chain(scene, [cam] * a.batch, 5, 0, 1, out)  # a chain of a frame loop
+    if a.single:
+        rd.render_tiles(scene, cam, 5, 0, 1, out)
+    else:
+        rd.render_tiles_chain(scene, [cam] * a.batch, 5, 0, 1, out)  # a chain of a frame loop
 torch.cuda.synchronize()
 print("frames done")
