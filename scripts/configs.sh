@@ -9,10 +9,11 @@ run() {
   grep '^{' gpurun_out/cfg.log >> gpurun_out/configs_$real.jsonl
 }
 rm -f gpurun_out/configs_$real.jsonl
-run --scene ch9 --width 1920 --height 1080 --steps 20 &&
-run --scene teapot_low --width 1920 --height 1080 --steps 20 &&
-run --scene teapot_high --width 3840 --height 2160 --steps 10 &&
-run --scene glass --width 1920 --height 1080 --steps 20 &&
-run --scene north_star --width 1920 --height 1080 --steps 20 &&
-run --scene north_star --width 3840 --height 2160 --steps 10 &&
-run --scene stress --width 7680 --height 4320 --steps 3 --warmup 1
+run --scene ch9 --width 1920 --height 1080 --steps 96 &&
+run --scene teapot_low --width 1920 --height 1080 --steps 96 &&
+run --scene teapot_high --width 3840 --height 2160 --steps 24 &&
+run --scene glass --width 1920 --height 1080 --steps 96 &&
+run --scene north_star --width 1920 --height 1080 --steps 96 &&
+run --scene north_star --width 3840 --height 2160 --steps 24 &&
+run --scene stress --width 7680 --height 4320 --steps 6 --warmup 2 &&
+run --scene teapot_field --width 1920 --height 1080 --steps 48
