@@ -84,7 +84,8 @@ struct rt355_ctx {
   // otherwise (100 000 small reflective shapes scatter the rays: packets are 11 to 42 % slower there).
   int packet_gens = -1;
   bool throughput_chain = false;  // the chain being queued was begun without waiting, or carries several frames
-  int combine_levels = 2;  // generations folded into the first combine launch by walking ray subtrees (0..3)
+  int combine_levels = 4;  // generations folded into the first combine launch by walking ray subtrees (0..4); 4 = the whole ray tree of a
+                           // depth-5 frame in ONE launch from generation 0: every hit record is read once and no colour is written back
   int shadow_lag = 0;   // the shadow launch of generation g is released behind the spawn of generation g + lag
   int merge_spawn = -1;  // the shadow launch of a generation also writes its reflected rays, k_spawn only the refracted ones: 1 always, 0 never,
                          // -1 for chains that overlap with others (one read of every hit for both, fewer launches; a frame rendered alone
@@ -284,6 +285,7 @@ int run_generations(rt355_ctx* c, const rt355_scene* s, RayPool<R>& pool, FrameC
     if ((rc = rec(RT355_K_COMBINE, g))) return rc;
     const int has_children = g < depth ? 1 : 0;
     switch (g == top ? levels : 0) {
+      case 4: hipLaunchKernelGGL((k_combine<R, 4>), dim3(grid), dim3(256), 0, c->stream, sc, pool, ctl, g, has_children, cam, out_mode, out_dev); break;
       case 3: hipLaunchKernelGGL((k_combine<R, 3>), dim3(grid), dim3(256), 0, c->stream, sc, pool, ctl, g, has_children, cam, out_mode, out_dev); break;
       case 2: hipLaunchKernelGGL((k_combine<R, 2>), dim3(grid), dim3(256), 0, c->stream, sc, pool, ctl, g, has_children, cam, out_mode, out_dev); break;
       case 1: hipLaunchKernelGGL((k_combine<R, 1>), dim3(grid), dim3(256), 0, c->stream, sc, pool, ctl, g, has_children, cam, out_mode, out_dev); break;

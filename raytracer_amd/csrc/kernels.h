@@ -985,6 +985,7 @@ struct BackwardVis {
 // microsecond on this chip, so one atomic per wave (32 400 for a 1080p frame) would by itself cost more
 // than the traversal.
 // ------------------------------------------------------------------------------------------------
+constexpr uint32_t WAVE_HAS_TRANSPARENT = 0x80000000u;  // in a wave's entry of blk_hits, above the count (at most 64)
 RT_FN unsigned long long lanes_below() { return (1ull << (threadIdx.x & 63u)) - 1ull; }
 RT_FN uint32_t wave_sum(uint32_t v) {
 #pragma unroll
@@ -1156,6 +1157,9 @@ RT_FN void trace_chunk(const DevScene<R>& sc, const RayPool<R>& pool, FrameCtl* 
   }
   // children of the wave's hits: a reflected ray per reflective hit, a refracted one per transparent hit
   wh = __popcll(__builtin_amdgcn_ballot_w64(hit)), wc = __popcll(__builtin_amdgcn_ballot_w64((n_child & 1u) != 0)) + 2u * __popcll(__builtin_amdgcn_ballot_w64((n_child & 2u) != 0));
+  // bit 31 of the hit count: some hit of the wave is on a transparent shape and may spawn (k_spawn<..., ONLY_T> looks at
+  // this word before it looks at any hit record)
+  if (__builtin_amdgcn_ballot_w64(hit && remaining > 0 && (vis.best_flags & PF_TRANSPARENT)) != 0ull) wh |= WAVE_HAS_TRANSPARENT;
 }
 
 // k_trace: trace_chunk over generation `gen`, one chunk per block and trip.  Every wave leaves the hit count and the
@@ -1192,7 +1196,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_trace_q(DevScene<R> sc, RayPool<R>
   Work wk;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   for (uint32_t base = blockIdx.x * BLOCK; base < count; base += gridDim.x * BLOCK) {
-    uint32_t wh = 0, wc = 0;  // this wave's hits and child-ray bound over the four passes
+    uint32_t wh = 0, wc = 0, wt = 0;  // this wave's hits and child-ray bound over the four passes; the flag of trace_chunk
     for (int sub = 0; sub < 4; ++sub) {
       const uint32_t i = base + wave * 64u + (uint32_t)sub * 16u + (lane >> 2);
       const bool valid = i < count;
@@ -1225,10 +1229,11 @@ __global__ void __launch_bounds__(BLOCK, 4) k_trace_q(DevScene<R> sc, RayPool<R>
       const bool spawns = hit && remaining > 0;
       wh += __popcll(__ballot(hit));
       wc += __popcll(__ballot(spawns && (vis.best_flags & PF_REFLECTIVE))) + __popcll(__ballot(spawns && (vis.best_flags & PF_TRANSPARENT)));
+      if (__ballot(spawns && (vis.best_flags & PF_TRANSPARENT)) != 0ull) wt = WAVE_HAS_TRANSPARENT;
     }
     if (lane == 0 && base + wave * 64u < count) {
       const uint32_t e = (base + wave * 64u) / GROUP;
-      pool.blk_hits[e] = wh;
+      pool.blk_hits[e] = wh | wt;
       pool.blk_children[e] = wc;
     }
   }
@@ -1298,6 +1303,7 @@ static __global__ void __launch_bounds__(1024) k_scan(const uint32_t* blk_hits, 
       for (uint32_t j = 0; j < 4u; ++j)
         if (k0 + j < n) c[j] = blk_children[k0 + j], h[j] = blk_hits[k0 + j];
     }
+    for (uint32_t j = 0; j < 4u; ++j) h[j] &= ~WAVE_HAS_TRANSPARENT;  // the flag above the count is k_spawn's
     const uint32_t csum = c[0] + c[1] + c[2] + c[3], hsum = h[0] + h[1] + h[2] + h[3];
     uint32_t ctot, htot;
     const uint32_t cinc = block_scan_1024(csum, s_scan, &ctot);
@@ -1916,16 +1922,31 @@ __global__ void __launch_bounds__(BLOCK, PACKET ? RT355_WPS_SPAWN_PACKET : RT355
   Work wk;
   uint32_t start, gcount;
   gen_range(ctl, gen, pool.capacity, start, gcount);
-  // the next trip's hit record is requested ahead, as in k_shadow
+  // Whether a wave of rays has anything to spawn is known from the words its trace left for k_scan -- the child bound,
+  // or for ONLY_T the flag above the hit count -- four bytes per 64 rays, read through the scalar cache two trips
+  // ahead; the hit records (eight bytes per ray) are requested one trip ahead, and only for waves that spawn.
+  // (Reading the words of 64 trips with one vector load and visiting only the trips that spawn is no faster where few
+  // waves spawn and 10 % slower where most do.)
+  static_assert(BLOCK == GROUP, "one entry of the bookkeeping per block and trip");
   const uint32_t stride = gridDim.x * BLOCK;
   uint32_t rbase = blockIdx.x * BLOCK;
+  auto spawns = [&](uint32_t base) -> bool {  // wave-uniform
+    if (base >= gcount) return false;
+    cptr<uint32_t> q = (cptr<uint32_t>)(const uint32_t*)(ONLY_T ? pool.blk_hits : pool.blk_children);
+    const uint32_t w = q[base / GROUP];
+    return ONLY_T ? (w & WAVE_HAS_TRANSPARENT) != 0u : w != 0u;
+  };
+  bool w_cur = spawns(rbase), w_next = spawns(rbase + stride);
   HitRec next = HitRec{-1, 0};
-  if (rbase < gcount) next = load_hit(pool, start + (rbase + threadIdx.x < gcount ? rbase + threadIdx.x : 0u));
+  if (w_cur) next = load_hit(pool, start + (rbase + threadIdx.x < gcount ? rbase + threadIdx.x : 0u));
   for (; rbase < gcount; rbase += stride) {
     const uint32_t i = rbase + threadIdx.x;
     const HitRec hit = next;
-    if (rbase + stride < gcount) next = load_hit(pool, start + (i + stride < gcount ? i + stride : 0u));
-    spawn_chunk<R, MODE, PACKET, ONLY_T>(sc, pool, ctl, gen, start, gcount, i, hit, any_transparent, lds, wk);
+    const bool w = w_cur;
+    w_cur = w_next;
+    if (w_cur) next = load_hit(pool, start + (i + stride < gcount ? i + stride : 0u));
+    w_next = spawns(rbase + 2u * stride);
+    if (w) spawn_chunk<R, MODE, PACKET, ONLY_T>(sc, pool, ctl, gen, start, gcount, i, hit, any_transparent, lds, wk);
   }
   flush_work<(MODE & M_COUNT) != 0>(ctl, launch, wk);
 }

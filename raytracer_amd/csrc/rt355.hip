@@ -526,7 +526,7 @@ int rt355_ctx_create_ex(rt355_ctx** out, int device_id, int real_bits, int flags
   // other entry point and the no-allocation one reports the reason.
   if (scratch_address(device_id, &c->fixed_scratch) != RT355_OK) c->fixed_scratch = nullptr, c->fixed_scratch_error = g_err;
   if (const char* e = getenv("RT355_PACKET_GENS")) c->packet_gens = std::max(0, std::min((int)RT355_MAX_GEN, atoi(e)));
-  if (const char* e = getenv("RT355_COMBINE_LEVELS")) c->combine_levels = std::max(0, std::min(3, atoi(e)));
+  if (const char* e = getenv("RT355_COMBINE_LEVELS")) c->combine_levels = std::max(0, std::min(4, atoi(e)));
   if (const char* e = getenv("RT355_SHADOW_LAG")) c->shadow_lag = std::max(0, atoi(e));
   if (const char* e = getenv("RT355_QUAD")) c->quad = atoi(e) & 3;
   if (const char* e = getenv("RT355_MERGE_SPAWN")) c->merge_spawn = atoi(e) != 0;

@@ -11,7 +11,10 @@ import json,sys
 l=[x for x in open('gpurun_out/v.log') if x.startswith('{')][-1]
 b=json.loads(l)
 c=b['config']
-print(f"{sys.argv[1]:24s} K={c['chains_in_flight']} B={c['frames_per_chain']} ms/step {b['ms_per_step']:.4f}  single {c['single_frame_ms']:.4f}  Mrays/s {b['value']:.0f}")
+r=b['roofline']
+agg={}
+for x in r['launches']: agg[x['kernel'][2:]]=agg.get(x['kernel'][2:],0)+x['ms']
+print(f"{sys.argv[1]:24s} K={c['chains_in_flight']} B={c['frames_per_chain']} ms/step {b['ms_per_step']:.4f}  single {c['single_frame_ms']:.4f}  Mrays/s {b['value']:.0f}  chain-sum/frame {r['frame_kernel_ms']:.4f}  " + " ".join(f"{k}:{v:.3f}" for k,v in agg.items()))
 PY
 done
 cat $out

@@ -304,9 +304,9 @@ def test_render_is_deterministic(dev):
 
 @pytest.mark.parametrize("env", [{"RT355_QUAD": "3"}, {"RT355_QUAD": "1"}, {"RT355_PACKET_GENS": "0", "RT355_QUAD": "3"},
                                  {"RT355_PACKET_GENS": "0"}, {"RT355_PACKET_GENS": "6"},
-                                 {"RT355_COMBINE_LEVELS": "0"}, {"RT355_PACKET_GENS": "1"}, {"RT355_MERGE_SPAWN": "1"},
+                                 {"RT355_COMBINE_LEVELS": "0"}, {"RT355_COMBINE_LEVELS": "2"}, {"RT355_PACKET_GENS": "1"}, {"RT355_MERGE_SPAWN": "1"},
                                  {"RT355_MERGE_SPAWN": "1", "RT355_PACKET_GENS": "0"}, {"RT355_MERGE_SPAWN": "1", "RT355_PACKET_GENS": "6"}],
-                         ids=["quad", "quad-trace", "quad-all", "per-lane-all", "packet-all", "combine-per-generation",
+                         ids=["quad", "quad-trace", "quad-all", "per-lane-all", "packet-all", "combine-per-generation", "combine-two-levels",
                               "packet-primary-only", "merged-spawn", "merged-spawn-per-lane", "merged-spawn-packets"])
 @pytest.mark.parametrize("real_bits", [64, 32])
 def test_every_launch_plan_renders_the_same_image(env, real_bits):
@@ -474,8 +474,8 @@ def test_deepest_recursion_with_instrumentation(dev, oracle):
     assert st.n_launch <= _abi.RT355_MAX_LAUNCH
     kinds = list(st.launch_kind[: st.n_launch])
     assert kinds.count(_abi.K_TRACE) == 8 and kinds.count(_abi.K_SPAWN) == 7
-    # the deepest generation shades in its trace; the first combine launch folds generations 4, 5 and 6
-    assert kinds.count(_abi.K_SHADE) == 7 and kinds.count(_abi.K_COMBINE) == 5
+    # the deepest generation shades in its trace; the first combine launch folds generations 2 to 6 (four levels below it)
+    assert kinds.count(_abi.K_SHADE) == 7 and kinds.count(_abi.K_COMBINE) == 3
     want, cnt, _ = oracle.render(world, cam, 7, dev.real_bits, threads=8)
     frac = mismatch(oracle.to_u8(plain), oracle.to_u8(want))
     assert frac <= (0.004 if dev.real_bits == 64 else 0.02)
