@@ -174,7 +174,9 @@ RT_FN T load_uniform(const T* p) {
 // emit(t, u, v, emission_index) is called once per intersection, in the reference's emission order.
 // ------------------------------------------------------------------------------------------------
 // UNIFORM: p is the same in every lane of the wave (the every-ray list, the leaves of a packet traversal).
-template <class R, int MODE, bool UNIFORM = false, class Emit>
+// NONNEG: the caller has no use for intersections with t < 0 (nearest hit and any hit ask for t >= 0,
+// src/intersection.rs:151); where the sign of t is known before t is, such an intersection is not computed.
+template <class R, int MODE, bool UNIFORM = false, bool NONNEG = false, class Emit>
 RT_FN void prim_hits(const DevScene<R>& sc, int p, int flags, V3<R> wo, V3<R> wd, Work& wk, Emit&& emit) {
   const int kind = flags & PF_KIND_MASK;
   if constexpr (MODE & M_COUNT) wk.prim[kind]++;
@@ -209,6 +211,11 @@ RT_FN void prim_hits(const DevScene<R>& sc, int p, int flags, V3<R> wo, V3<R> wd
   switch (kind) {
     case RT355_PLANE: {  // src/shape.rs:210-217
       if (fabs(d.y) < EPS) return;
+      // t = -o.y / d.y is negative exactly when o.y and d.y have the same sign and o.y is not zero (a zero o.y gives
+      // t = +-0.0, which counts as t >= 0): a ray leaving the floor upwards is told so without the division, which
+      // takes some thirty instructions in double
+      if constexpr (NONNEG)
+        if (o.y != R(0) && ((o.y < R(0)) == (d.y < R(0)))) return;
       emit(-o.y / d.y, R(0), R(0), 0);
       return;
     }
@@ -837,13 +844,13 @@ struct ClosestVis {
   }
   RT_FN bool prim(int p) {
     const PrimInfo info = sc.prim_info[p];
-    prim_hits<R, MODE>(sc, p, info.flags, o, d, wk, [&](R t, R u, R v, int) { accept(t, u, v, p, info.shape, info.flags); });
+    prim_hits<R, MODE, false, true>(sc, p, info.flags, o, d, wk, [&](R t, R u, R v, int) { accept(t, u, v, p, info.shape, info.flags); });
     return false;
   }
   // p is the same in every lane of the wave
   RT_FN bool prim_u(int p) {
     const PrimInfo info = load_uniform(&sc.prim_info[p]);
-    prim_hits<R, MODE, true>(sc, p, info.flags, o, d, wk, [&](R t, R u, R v, int) { accept(t, u, v, p, info.shape, info.flags); });
+    prim_hits<R, MODE, true, true>(sc, p, info.flags, o, d, wk, [&](R t, R u, R v, int) { accept(t, u, v, p, info.shape, info.flags); });
     return false;
   }
   RT_FN bool tri(int p, const DevTri& T) {
@@ -893,14 +900,14 @@ struct AnyVis {
   RT_FN R tmax() const { return limit; }
   RT_FN bool prim(int p) {
     const PrimInfo info = sc.prim_info[p];
-    prim_hits<R, MODE>(sc, p, info.flags, o, d, wk, [&](R t, R, R, int) {
+    prim_hits<R, MODE, false, true>(sc, p, info.flags, o, d, wk, [&](R t, R, R, int) {
       if (t >= R(0) && t < limit) found = true;
     });
     return found;
   }
   RT_FN bool prim_u(int p) {
     const PrimInfo info = load_uniform(&sc.prim_info[p]);
-    prim_hits<R, MODE, true>(sc, p, info.flags, o, d, wk, [&](R t, R, R, int) {
+    prim_hits<R, MODE, true, true>(sc, p, info.flags, o, d, wk, [&](R t, R, R, int) {
       if (t >= R(0) && t < limit) found = true;
     });
     return found;
@@ -1456,14 +1463,16 @@ RT_FN R pow_shininess(R x, R y) {
 }
 
 // Material::lighting (src/material.rs:108-162)
+// lightv_known: normalize(light - point) when the caller holds it already (the direction of the shadow ray it has just
+// traced from the same point is that very expression, src/world.rs:46-49), else null.
 template <class R>
-RT_FN V3<R> lighting(const DevScene<R>& sc, const DevMaterial<R>& m, V3<R> point, V3<R> eyev, V3<R> normalv, bool shadowed) {
+RT_FN V3<R> lighting(const DevScene<R>& sc, const DevMaterial<R>& m, V3<R> point, V3<R> eyev, V3<R> normalv, bool shadowed, const V3<R>* lightv_known = nullptr) {
   const V3<R> c = m.pattern_kind != RT355_PATTERN_NONE ? pattern_at(m, point) : ld3(m.color);
   const V3<R> li = ld3(sc.light_int);
   const V3<R> eff = {c.x * li.x, c.y * li.y, c.z * li.z};
   const V3<R> ambient = eff * m.ambient;
   if (shadowed) return ambient;
-  const V3<R> lightv = normalize(ld3(sc.light_pos) - point);
+  const V3<R> lightv = lightv_known ? *lightv_known : normalize(ld3(sc.light_pos) - point);
   const R ldn = dot(lightv, normalv);
   V3<R> diffuse = {R(0), R(0), R(0)}, specular = {R(0), R(0), R(0)};
   if (ldn >= R(0)) {
@@ -1606,7 +1615,7 @@ RT_FN void shade_surface(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t
     // the whole record at once: read field by field as lighting() comes to them, every field is a memory round trip
     // of its own behind the branch that needs it (pattern kind, then its colours, then ambient, diffuse, shininess ...)
     const DevMaterial<R> m = load_whole(&sc.materials[flags >> PF_MAT_SHIFT]);
-    st3(pool.color + 3ull * r, lighting(sc, m, pc.over_point, eyev, normalv, av.found));
+    st3(pool.color + 3ull * r, lighting(sc, m, pc.over_point, eyev, normalv, av.found, &ldir));
 #endif
   }
 }
