@@ -1674,7 +1674,10 @@ RT_FN void container_indices(const DevScene<R>& sc, bool need, int p, PrimInfo i
   // Reversed ray: 0 - d, so that a zero component stays +0.0 (negation would make it -0.0, and the cube's
   // slab test, which branches on d >= 0 (src/shape.rs:455-466), tells the two apart).
   const V3<R> rd = {R(0) - d.x, R(0) - d.y, R(0) - d.z};
-  bool searching = need && !(others_unit && !h_before), found = false;
+  // nor when the hit shape's box holds no intersection of any other prim (PF_ISOLATED, decided at upload): the stretch
+  // between two of the shape's own intersections lies inside that box
+  const bool isolated = (info.flags & PF_ISOLATED) != 0;
+  bool searching = need && !(others_unit && (!h_before || isolated)), found = false;
   int other_flags = 0, other_s = -1;
   R other_t = R(0);
   R bound_t = t;

@@ -378,6 +378,7 @@ int upload_impl(rt355_ctx* c, const HostScene& hs, rt355_scene* s) {
     }
     for (int k = 0; k < 4; ++k) nodes[i].pad[k] = 0;
   }
+  if ((int64_t)nm > MAX_MATERIALS) return set_err(RT355_ECAPACITY, "more than " + std::to_string(MAX_MATERIALS) + " distinct materials");
   std::vector<PrimInfo> info(np);
   int64_t n_secondary = 0;
   std::vector<DevXform<R>> xf(np);
@@ -398,6 +399,55 @@ int upload_impl(rt355_ctx* c, const HostScene& hs, rt355_scene* s) {
   for (size_t i = 0; i < np; ++i) n_optical += hs.materials[hs.prims[i].material].refractive != 1.f;
   for (size_t i = 0; i < np; ++i)
     if (n_optical == (hs.materials[hs.prims[i].material].refractive != 1.f ? 1u : 0u)) info[i].flags |= PF_OTHERS_UNIT;
+  // PF_ISOLATED.  The n1 / n2 search of a ray that leaves a transparent shape looks for intersections of OTHER shapes on
+  // the stretch between two of the shape's own intersections.  Both ends lie on the shape, so the stretch lies inside the
+  // shape's bounding box; when no other prim can have an intersection there, the search is skipped.  Decided here, once:
+  // bounded prims by their boxes (with a margin far above the rounding of any intersection), planes by the side of the
+  // plane the box's corners lie on; any other unbounded prim counts as reaching everywhere.  Spheres, cubes and
+  // cylinders only: a cone's parallel-ray intersection (src/shape.rs:295-298) can lie outside its box.  Few transparent
+  // prims only: the test is quadratic.
+  {
+    std::vector<size_t> cand;
+    const size_t n_top = (size_t)hs.n_top;
+    for (size_t i = 0; i < n_top && cand.size() <= 64; ++i) {
+      const int kind = hs.prims[i].flags & PF_KIND_MASK;
+      if ((info[i].flags & PF_TRANSPARENT) && (info[i].flags & PF_OTHERS_UNIT) && hs.prims[i].bounded &&
+          (kind == RT355_SPHERE || kind == RT355_CUBE || kind == RT355_CYLINDER))
+        cand.push_back(i);
+    }
+    if (cand.size() <= 64)
+      for (size_t i : cand) {
+        const HostPrim& a = hs.prims[i];
+        double lo[3], hi[3];
+        for (int k = 0; k < 3; ++k) {
+          const double m = 1e-3 + 1e-6 * std::max(std::fabs(a.lo[k]), std::fabs(a.hi[k]));
+          lo[k] = a.lo[k] - m, hi[k] = a.hi[k] + m;
+        }
+        bool isolated = true;
+        for (size_t j = 0; j < n_top && isolated; ++j) {
+          if (j == i) continue;
+          const HostPrim& b = hs.prims[j];
+          if (b.bounded) {
+            bool apart = false;
+            for (int k = 0; k < 3; ++k) apart = apart || b.hi[k] < lo[k] || b.lo[k] > hi[k];
+            isolated = apart;
+          } else if ((b.flags & PF_KIND_MASK) == RT355_PLANE) {
+            // object-space height of the box's corners above the plane y = 0 (row 1 of the inverse transformation)
+            int above = 0, below = 0;
+            for (int c8 = 0; c8 < 8; ++c8) {
+              const double x = (c8 & 1) ? hi[0] : lo[0], y = (c8 & 2) ? hi[1] : lo[1], z = (c8 & 4) ? hi[2] : lo[2];
+              const double h = b.inv[4] * x + b.inv[5] * y + b.inv[6] * z + b.inv[7];
+              const double m = 1e-6 * (std::fabs(b.inv[4] * x) + std::fabs(b.inv[5] * y) + std::fabs(b.inv[6] * z) + std::fabs(b.inv[7])) + 1e-12;
+              above += h > m, below += h < -m;
+            }
+            isolated = above == 8 || below == 8;
+          } else {
+            isolated = false;
+          }
+        }
+        if (isolated) info[i].flags |= PF_ISOLATED;
+      }
+  }
   std::vector<DevTri> tri(any_tri ? np : 0);
   std::vector<DevTriNormals<R>> trin(any_tri ? np : 0);
   if (any_tri)

@@ -56,7 +56,10 @@ constexpr int PF_OTHERS_UNIT = 128;  // every OTHER prim of the scene has refrac
 constexpr int PF_SCHLICK = 256;      // reflective > 0 && transparency > 0: the two child colours are mixed by schlick()
 constexpr int PF_INSTANCED = 512;    // a triangle of an instanced mesh: identity inside its mesh's own tree, taken to world space by
                                      // the transformation of its instance (inst_of[p] is the instance's prim)
-constexpr int PF_MAT_SHIFT = 10;
+constexpr int PF_ISOLATED = 1024;    // (transparent prims) no other prim can have an intersection inside this prim's bounding box: the n1 / n2
+                                     // search between two of the prim's own intersections has nothing to find
+constexpr int PF_MAT_SHIFT = 11;
+constexpr int64_t MAX_MATERIALS = 1ll << (31 - PF_MAT_SHIFT);  // distinct materials of a scene (the id sits above the flags in 32 bits)
 // Device-side prim kind of an instanced mesh: a run of triangles of World.shapes that share one transformation (what
 // Scene::to_transformed_shapes leaves of a group with a mesh below it, src/group.rs:117-168) is kept in object space
 // under a tree of its own; the top tree holds one prim for it.  Groups themselves never reach the device

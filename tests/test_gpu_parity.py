@@ -596,6 +596,52 @@ def test_refractive_indices_with_overlapping_shapes(dev, oracle, second_index):
     assert bad <= (0.003 if dev.real_bits == 64 else 0.03)
 
 
+@pytest.mark.parametrize("case", ["apart", "floor-through-the-glass", "cube-inside-the-glass", "cube-touching-the-box"])
+@pytest.mark.parametrize("glass_kind", ["sphere", "cube", "cylinder"])
+def test_refractive_indices_of_a_glass_shape_alone_in_its_box(dev, oracle, case, glass_kind):
+    """A ray leaving a transparent shape looks for other shapes entered on the stretch inside it
+    (src/intersection.rs:86-127).  When no other shape reaches into the glass shape's bounding box the device
+    decides at upload that there is nothing to find and skips the search; a floor cutting through the glass, an
+    opaque cube inside it or one that reaches into the corner of its box must keep the search.  Rays start inside
+    and outside the glass; every case must give the oracle's colours."""
+    glass = Material.new_glass()
+    glass.reflective = 0.4
+    make = {"sphere": lambda t: Shape.Sphere(t, glass), "cube": lambda t: Shape.Cube(t, glass),
+            "cylinder": lambda t: Shape.Cylinder(t, glass, -1.0, 1.0, True)}[glass_kind]
+    floor = Material(color=(0.9, 0.9, 0.9), reflective=0.2)
+    floor.pattern = Pattern.Checker((1, 1, 1), (0.1, 0.1, 0.1))
+    red = Material(color=(0.8, 0.3, 0.2))
+    shapes = [make(mx.rotation_y(0.4) @ mx.scaling(1.0, 1.2, 1.0)),
+              Shape.Plane(mx.translation(0, -0.4 if case == "floor-through-the-glass" else -2.0, 0), floor)]
+    if case == "cube-inside-the-glass":
+        shapes.append(Shape.Cube(mx.translation(0.1, 0.2, 0.0) @ mx.scaling(0.3, 0.3, 0.3), red))
+    elif case == "cube-touching-the-box":  # inside the glass shape's box, outside a sphere or cylinder
+        shapes.append(Shape.Cube(mx.translation(1.35, 1.3, 1.35) @ mx.scaling(0.25, 0.25, 0.25), red))
+    else:
+        shapes.append(Shape.Cube(mx.translation(3.0, 0.0, 1.0) @ mx.scaling(0.5, 0.5, 0.5), red))
+    world = World(PointLight((-4, 6, -5), (1, 1, 1)), shapes)
+    rng = np.random.default_rng(23)
+    n = 4000
+    org = rng.uniform(-2.5, 2.5, (n, 3))
+    org[: n // 2] *= 0.3
+    tgt = rng.uniform(-1.0, 1.0, (n, 3))
+    d = tgt - org
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, d], axis=1).astype(np.float32)
+    scene = dev.upload(world)
+    dev.set_pool(64.0)
+    try:
+        got = scene.color_at(rays, 5)
+    finally:
+        dev.set_pool(8.0)
+        scene.close()
+    want = oracle.color_at(world, rays, 5, dev.real_bits)
+    tol = 1e-4 if dev.real_bits == 64 else 2e-2
+    bad = (np.abs(got - want).max(axis=1) > tol).mean()
+    print(f"glass {glass_kind}, {case}, real={dev.real_bits}: {bad:.3%} of {n} rays differ by more than {tol}")
+    assert bad <= (0.003 if dev.real_bits == 64 else 0.03)
+
+
 def test_cpp_host_mirror_renders_like_the_python_one(tmp_path):
     """include/rt355.hpp: the reference's camera test (src/camera.rs:155-169) and its default scene
     (src/main.rs:202-273) written against the C++ mirror; the canvas must equal the one the Python mirror
