@@ -630,16 +630,22 @@ def test_refractive_indices_of_a_glass_shape_alone_in_its_box(dev, oracle, case,
     rays = np.concatenate([org, d], axis=1).astype(np.float32)
     scene = dev.upload(world)
     dev.set_pool(64.0)
+    dev.set_counting(True)
+    st = Stats()
     try:
-        got = scene.color_at(rays, 5)
+        got = scene.color_at(rays, 5, st)
     finally:
+        dev.set_counting(False)
         dev.set_pool(8.0)
         scene.close()
     want = oracle.color_at(world, rays, 5, dev.real_bits)
     tol = 1e-4 if dev.real_bits == 64 else 2e-2
     bad = (np.abs(got - want).max(axis=1) > tol).mean()
-    print(f"glass {glass_kind}, {case}, real={dev.real_bits}: {bad:.3%} of {n} rays differ by more than {tol}")
+    # the search is the only traversal of the spawn launches: their box tests tell whether it ran
+    searched = sum(int(st.launch_box_tests[i]) for i in range(st.n_launch) if st.launch_kind[i] == _abi.K_SPAWN)
+    print(f"glass {glass_kind}, {case}, real={dev.real_bits}: {bad:.3%} of {n} rays differ by more than {tol}; box tests of the n1/n2 search: {searched}")
     assert bad <= (0.003 if dev.real_bits == 64 else 0.03)
+    assert (searched == 0) == (case == "apart")
 
 
 def test_cpp_host_mirror_renders_like_the_python_one(tmp_path):
