@@ -1726,7 +1726,7 @@ RT_FN void container_indices(const DevScene<R>& sc, bool need, int p, PrimInfo i
 // prepared hit are read and made once for both.  Chains that overlap with others run this way; k_spawn is then left
 // with the transparent hits alone.
 template <class R, int MODE, bool PACKET, bool SPAWN>
-__global__ void __launch_bounds__(BLOCK, PACKET ? RT355_WPS_PACKET : RT355_WPS_LANE) k_shadow(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int launch) {
+__global__ void __launch_bounds__(BLOCK, PACKET ? RT355_WPS_SHADOW_PACKET : RT355_WPS_LANE) k_shadow(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int launch) {
   uint32_t start, gcount;
   gen_range(ctl, gen, pool.capacity, start, gcount);
   __shared__ int lds_stack[PACKET ? PARK_INTS : LDS_STACK * BLOCK];  // packets: shade_surface parks two vectors per lane here
@@ -2021,7 +2021,7 @@ RT_FN V3<R> ray_colour(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t r
 // colours are final already).  With LEVELS = n the generations gen+1 .. gen+n need no launch of their own,
 // and generation gen+n+1 must be final (the deepest one, shaded inside its trace launch).
 template <class R, int LEVELS>
-__global__ void __launch_bounds__(256) k_combine(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int has_children, DevCamera<R> cam, int mode, float* out) {
+__global__ void __launch_bounds__(256, RT355_WPS_COMBINE) k_combine(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int has_children, DevCamera<R> cam, int mode, float* out) {
   uint32_t start, gcount;
   gen_range(ctl, gen, pool.capacity, start, gcount);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < gcount; i += gridDim.x * blockDim.x) {

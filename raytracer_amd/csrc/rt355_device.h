@@ -33,8 +33,17 @@ constexpr int GROUP = 64;            // rays per entry of the child-slot bookkee
 #ifndef RT355_WPS_PACKET
 #define RT355_WPS_PACKET 4
 #endif
+#ifndef RT355_WPS_COMBINE
+#define RT355_WPS_COMBINE 4
+#endif
+// the packet shadow kernel gains from a fifth wave although 28 of its registers then live in scratch memory (generation 0
+// of the headline: 1.33 -> 1.2 ms per chain of 16 frames; six waves are no better); the packet spawn kernels lose by it
+#ifndef RT355_WPS_SHADOW_PACKET
+#define RT355_WPS_SHADOW_PACKET 5
+#endif
+// the deepest generation's trace-and-shade kernel: 128 registers and ten spilled beat 140 and three waves (0.73 -> 0.66 ms)
 #ifndef RT355_WPS_PACKET_LAST
-#define RT355_WPS_PACKET_LAST 3
+#define RT355_WPS_PACKET_LAST 4
 #endif
 #ifndef RT355_WPS_SPAWN_PACKET
 #define RT355_WPS_SPAWN_PACKET 4
