@@ -2019,7 +2019,8 @@ RT_FN V3<R> ray_colour(const DevScene<R>& sc, const RayPool<R>& pool, uint32_t r
 
 // LEVELS: how many generations below `gen` are folded in by walking each ray's own subtree (0: the children's
 // colours are final already).  With LEVELS = n the generations gen+1 .. gen+n need no launch of their own,
-// and generation gen+n+1 must be final (the deepest one, shaded inside its trace launch).
+// and generation gen+n+1 must be final (the deepest one, shaded inside its trace launch).  The default folds four:
+// a frame of max_depth 5 is combined by one launch from generation 0.
 template <class R, int LEVELS>
 __global__ void __launch_bounds__(256, RT355_WPS_COMBINE) k_combine(DevScene<R> sc, RayPool<R> pool, FrameCtl* ctl, int gen, int has_children, DevCamera<R> cam, int mode, float* out) {
   uint32_t start, gcount;
