@@ -41,21 +41,25 @@ FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 (FMA) x 2.4 GHz
 KIND_NAME = {1: "k_trace", 2: "k_shadow", 3: "k_combine", 5: "k_spawn", 6: "k_scan"}
 
 
-def cpu_baseline(world, cam, depth):
+def cpu_baseline(world, cam, depth, strict_uv=False):
     """The CPU restatement of the reference path (oracle/, float = the reference's precision, brute
-    force, recursive, 1 thread like the reference) on a bounded window of the same frame."""
+    force, recursive, 1 thread like the reference) on a bounded window of the same frame.
+    strict_uv: smooth-triangle normals from the u, v of the line's first intersection, as the reference literally does
+    (src/intersection.rs:67-71); hits where it would panic are counted and shaded with the hit's own u, v."""
     import oracle
     w, h = int(cam.horizontal_size), int(cam.vertical_size)
     ww, wh = max(1, w // 4), max(1, h // 4)
     x0, y0 = (w - ww) // 2, int(h * 0.55) - wh // 2
     win = (x0, x0 + ww, y0, y0 + wh)
-    _, cnt, sec = oracle.render(world, cam, depth, 32, 0, win, threads=1)
+    flags = oracle.STRICT_UV if strict_uv else 0
+    _, cnt, sec = oracle.render(world, cam, depth, 32, flags, win, threads=1)
     rays = int(cnt["radiance"].sum() + cnt["hits"].sum())
     # the same window on all the cores this job may use (rows handed out to threads): the reference itself has no
     # threading, this is the restatement's figure, labelled so
     n_thr = max(1, min(16, os.cpu_count() or 1))
-    _, _, sec_all = oracle.render(world, cam, depth, 32, 0, win, threads=n_thr)
+    _, _, sec_all = oracle.render(world, cam, depth, 32, flags, win, threads=n_thr)
     return {"value": round(rays / sec / 1e6, 6), "unit": "Mrays/s", "cores": 1, "kind": "port",
+            **({"strict_uv": True, "hits_where_the_reference_panics": int(cnt["panics"])} if strict_uv else {}),
             "sample": f"{ww}x{wh} pixel window at ({x0},{y0}) of the same {w}x{h} frame, {rays} rays, "
                       f"{sec:.1f} s, float, brute force over {world.n_shapes()} shapes, 1 thread",
             "all_cores": {"value": round(rays / sec_all / 1e6, 6), "unit": "Mrays/s", "cores": n_thr, "kind": "port (restatement, threads over rows)",
@@ -78,6 +82,13 @@ def main():
                     help="what a step leaves on rank 0: the float canvas (Canvas.pixels) or its Color::to_u8 bytes, the body of the PPM the "
                          "reference writes per frame.  auto: float on one GPU (rendered in place, nothing to gather), u8 on several (the tiles "
                          "are converted where they are rendered and a quarter of the bytes cross xGMI)")
+    ap.add_argument("--ref-parser-quirk", action="store_true",
+                    help="triangulate the OBJ meshes the way the reference's parser does (polygons fanned over the global vertex list, "
+                         "src/wavefront.rs:101-116): the scene the reference itself would build from the file")
+    ap.add_argument("--strict-uv-quirk", action="store_true",
+                    help="the CPU baseline interpolates smooth-triangle normals with the u, v of the line's first intersection as the "
+                         "reference literally does (src/intersection.rs:67-71) and reports the hits where the reference would panic; "
+                         "the device always uses the hit's own u, v (declared deviation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the 3840x2160 figure that is reported beside the headline")
     ap.add_argument("--rehearse", action="store_true",
@@ -98,6 +109,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    scenes.REF_PARSER_QUIRK = args.ref_parser_quirk
     world, cam = scenes.CONFIGS[args.scene](args.width, args.height)
     w, h = args.width, args.height
     dev = Device.get(local_rank, args.real)
@@ -183,6 +195,7 @@ def main():
             "config": {"workload": f"{args.scene} {w}x{h} depth {args.depth}: teapot-high.obj (6320 smooth triangles) + "
                                    "reflective checker floor + glass sphere, shadows" if args.scene == "north_star"
                        else f"{args.scene} {w}x{h} depth {args.depth}",
+                       "ref_parser_quirk": bool(args.ref_parser_quirk),
                        "shapes": world.n_shapes(), "rays_per_frame": rays_frame, "primary_rays_per_frame": primary_frame,
                        "primary_mrays_per_s": round(primary_frame / (ms * 1e-3) / 1e6, 3),
                        "parallelism": f"tile{world_size}",
@@ -277,7 +290,7 @@ def main():
         if world_size == 1 and headline and not args.no_extra:
             out["config"]["also"] = _other_sizes(dev, scene, args)
         if not args.no_cpu_baseline and world_size == 1:
-            out["cpu_baseline"] = cpu_baseline(world, cam, args.depth)
+            out["cpu_baseline"] = cpu_baseline(world, cam, args.depth, args.strict_uv_quirk)
         print(json.dumps(out))
     if world_size > 1:
         dist.barrier()

@@ -63,15 +63,19 @@ def ch11(width=600, height=450):
 
 
 _mesh_cache = {}
+# True: the meshes are triangulated the way the reference's parser does it -- polygons fanned over the GLOBAL vertex
+# list instead of the face's own (src/wavefront.rs:101-116, :143-155); the scenes are then the ones the reference would
+# build from the same files (bench.py --ref-parser-quirk).
+REF_PARSER_QUIRK = False
 
 
 def _teapot(name, y_up):
     """Smooth-triangle list of a teapot OBJ.  The files are Z-up; `y_up` bakes (x,y,z) -> (x,z,-y) into
     the vertices AND the vertex normals, because the reference never transforms triangle normals
     (src/shape.rs:198-203), so a shape transformation cannot be used to re-orient a mesh."""
-    key = (name, y_up)
+    key = (name, y_up, REF_PARSER_QUIRK)
     if key not in _mesh_cache:
-        w = Wavefront.parse(os.path.join(ASSETS, name))
+        w = Wavefront.parse(os.path.join(ASSETS, name), ref_parser_quirk=REF_PARSER_QUIRK)
         shapes = w.shapes
         if y_up:
             rot = lambda p: (p[0], p[2], -p[1])
