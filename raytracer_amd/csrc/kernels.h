@@ -44,10 +44,23 @@ template <class R> RT_FN R dot(V3<R> a, V3<R> b) { return a.x * b.x + a.y * b.y 
 template <class R> RT_FN V3<R> cross(V3<R> a, V3<R> b) {  // src/tuple.rs:42-48
   return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
+// 1 / sqrt(x).  In double: the hardware's estimate (v_rsq_f64, some 26 bits) and two Newton steps, good to about an
+// ulp like the square root followed by the division it stands for, at a dozen instructions instead of some fifty.
+// Zero gives NaN (infinity times zero in the first step), which is what the callers' zero vectors are meant to become.
+template <class R> RT_FN R inv_sqrt(R x) { return R(1) / sqrt(x); }
+template <> RT_FN double inv_sqrt<double>(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const double e = __builtin_fma(-(x * y), y, 1.0);  // 1 - x y^2
+    y = __builtin_fma(0.5 * y, e, y);
+  }
+  return y;
+}
 // nalgebra's normalize (no zero guard: a zero vector gives NaN).  The three quotients by the common norm are formed
-// with one reciprocal (within an ulp of the divisions; a division costs ten instructions in double).
+// with one reciprocal (within an ulp of the divisions).
 template <class R> RT_FN V3<R> normalize(V3<R> a) {
-  const R inv = R(1) / sqrt(dot(a, a));
+  const R inv = inv_sqrt(dot(a, a));
   return {a.x * inv, a.y * inv, a.z * inv};
 }
 template <class R> RT_FN V3<R> reflect(V3<R> v, V3<R> n) {  // src/tuple.rs:38-40
@@ -1534,10 +1547,12 @@ RT_FN Prepared<R> prepare(const DevScene<R>& sc, const HitRay<R>& h, int p, int 
 // distance + EPSILON (src/world.rs:52).
 template <class R>
 RT_FN void light_ray(const DevScene<R>& sc, V3<R> point, V3<R>& ldir, R& limit) {
+  // the same expression as normalize(): lighting() may take ldir for its lightv
   const V3<R> lv = ld3(sc.light_pos) - point;
-  const R distance = sqrt(dot(lv, lv));
-  ldir = lv * (R(1) / distance);
-  limit = distance + eps<R>();
+  const R dd = dot(lv, lv);
+  const R inv = inv_sqrt(dd);
+  ldir = {lv.x * inv, lv.y * inv, lv.z * inv};
+  limit = dd * inv + eps<R>();  // the distance (src/world.rs:47), within an ulp or two, + EPSILON
 }
 
 // Where the child rays of a wave's hits go: generation gen + 1 starts at child_start, this wave's children at

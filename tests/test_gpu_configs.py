@@ -382,9 +382,21 @@ def test_axis_parallel_ray_through_glass_inside_a_refractive_cube(oracle):
             scene.close()
         want = oracle.color_at(world, rays, 5, real_bits)
         off = np.abs(got - want).max(axis=1) > (1e-5 if real_bits == 64 else 5e-3)
+        # A ray of this axis-aligned arrangement may lie EXACTLY on a discontinuity of the image (ray 7, through
+        # x = y = 0.5, does from the fourth bounce on): which side it falls on is decided by the last bit of a
+        # normalised vector, and the device forms 1 / |v| differently from the oracle (both good to an ulp).  Such a ray
+        # must then carry the colour of one of the two sides: the oracle's own colours a step of 1e-4 to either side
+        # of the ray must differ from each other, and the device must match one of them.
+        for k in np.nonzero(off)[0]:
+            o, d = rays[k, :3].astype(np.float64), rays[k, 3:].astype(np.float64)
+            side = np.eye(3)[np.argsort(np.abs(d))[:2]]  # the two axes across the ray
+            near = np.asarray([list(o + s * 1e-4 * a) + list(d) for a in side for s in (-1.0, 1.0)], dtype=np.float32)
+            sides = oracle.color_at(world, near, 5, real_bits)
+            assert np.abs(sides - sides[0]).max() > 1e-2, (real_bits, k, "differs from the oracle away from any discontinuity", got[k], want[k])
+            assert np.abs(sides - got[k]).max(axis=1).min() < 1e-3, (real_bits, k, got[k], sides)
         # in f32 the oracle itself changes its answer for the last of these rays (it differs from its own f64
         # result): a threshold of this axis-aligned arrangement flips with single-precision rounding
-        assert off.sum() <= (0 if real_bits == 64 else 1), (real_bits, got, want)
+        assert off.sum() <= 1, (real_bits, got, want)
 
 
 def test_negative_coefficients_follow_the_reference(oracle):
