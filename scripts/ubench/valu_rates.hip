@@ -197,6 +197,50 @@ template <class K> void run(const char* name, K kern, double* out) {
   printf("%-16s %8.3f ms   %6.2f cycles per wave instruction at 2.4 GHz\n", name, ms, ms * 1e-3 * 2.4e9 / per_simd);
 }
 
+
+// dependent chains: every instruction reads the result of the one before it
+__global__ void __launch_bounds__(256) k_chain_fma64(double* out, int iters, float seed) {
+  double a = seed, b = 1.0000001, c = 1e-9;
+  for (int it = 0; it < iters; ++it) {
+#define B(k) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
+    REP16(B)
+#undef B
+  }
+  if (a == 12345.678) out[threadIdx.x] = a;
+}
+__global__ void __launch_bounds__(256) k_chain_fma32(double* out, int iters, float seed) {
+  float a = seed, b = 1.0000001f, c = 1e-9f;
+  for (int it = 0; it < iters; ++it) {
+#define B(k) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
+    REP16(B)
+#undef B
+  }
+  if (a == 12345.678f) out[threadIdx.x] = a;
+}
+__global__ void __launch_bounds__(256) k_chain_mix(double* out, int iters, float seed) {  // vector, scalar, vector, scalar ...
+  double a = seed, b = 1.0000001, c = 1e-9;
+  int s = __builtin_amdgcn_readfirstlane(iters);
+  for (int it = 0; it < iters; ++it) {
+#define B(k) asm volatile("v_fma_f64 %0, %0, %2, %3\n s_add_i32 %1, %1, 3" : "+v"(a), "+s"(s) : "v"(b), "v"(c) : "scc");
+    REP16(B)
+#undef B
+  }
+  if (a == 12345.678) out[threadIdx.x] = a + s;
+}
+template <class K> void run_waves(const char* name, K kern, double* out, int per_instr) {
+  for (int wps : {1, 2, 4, 5, 8}) {
+    const int iters = 4000, blocks = 256 * wps;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, 10, 1.5f);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, iters, 1.5f);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    printf("%-22s %d waves per SIMD: %6.2f cycles per instruction of one wave, %6.2f per instruction of the SIMD (2.4 GHz)\n", name, wps,
+           ms * 1e-3 * 2.4e9 / ((double)iters * 16 * per_instr), ms * 1e-3 * 2.4e9 / ((double)iters * 16 * per_instr * wps));
+  }
+}
+
 int main() {
   double* out; hipMalloc(&out, 4096);
   run("v_fma_f64", k_fma64, out); run("v_mul_f64", k_mul64, out); run("v_add_f64", k_add64, out); run("v_max_f64", k_max64, out);
@@ -207,6 +251,8 @@ int main() {
   run("v_readlane_b32", k_readlane, out);
   run("v_cndmask e64 sgpr", k_cndmask_sgpr, out); run("v_cmp+v_cndmask", k_cmp_cndmask, out); run("v_fma_f32 sgpr op", k_fma32_sgpr, out);
   run("v_min3_f32", k_min3_32, out); run("v_add_f32", k_add32, out); run("v_and_b32", k_and32, out);
+  run_waves("chain v_fma_f64", k_chain_fma64, out, 1); run_waves("chain v_fma_f32", k_chain_fma32, out, 1);
+  run_waves("chain fma64+s_add", k_chain_mix, out, 2);
   hipFree(out);
   return 0;
 }
