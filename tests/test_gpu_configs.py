@@ -554,6 +554,49 @@ def _instancing(on):
         os.environ["RT355_INSTANCE_MIN"] = str(1 << 30)
 
 
+@pytest.mark.parametrize("where", ["between-the-teapots", "inside-a-teapots-box"])
+@pytest.mark.parametrize("real_bits", [64, 32])
+def test_glass_ball_among_instanced_meshes(oracle, real_bits, where):
+    """A glass ball in a field of instanced teapots: n1 / n2 (src/intersection.rs:86-127) in the kernels that walk two
+    levels of trees.  Between the teapots nothing reaches into the ball's box and the search inside it is decided at
+    upload; moved into the (world-space) box of one instance -- though not into the teapot itself -- the search must run
+    and descend into that mesh.  Colours of rays from all around against the oracle, which knows neither trees nor
+    instances."""
+    world, cam = scenes.teapot_field(160, 90, "teapot-low.obj", 2)
+    g = Material.new_glass()
+    g.reflective = 0.5
+    # instance boxes of the 2 x 2 field sit around (+-26, ., +-26); the teapots are about 35 wide before scaling
+    centre = (0.0, 9.0, 0.0) if where == "between-the-teapots" else (26.0 - 9.0, 14.0, -26.0 + 12.0)
+    world.shapes.append(Shape.Sphere(mx.translation(*centre) @ mx.scaling(4.0, 4.0, 4.0), g))
+    rng = np.random.default_rng(29)
+    n = 4000
+    tgt = np.asarray(centre) + rng.normal(size=(n, 3)) * 2.5
+    org = np.asarray(centre) + rng.normal(size=(n, 3)) * 14.0
+    org[: n // 4] = np.asarray(centre) + rng.normal(size=(n // 4, 3)) * 1.5  # a quarter of the rays start inside the ball
+    d = tgt - org
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, d], axis=1).astype(np.float32)
+    dev = Device.get(0, real_bits)
+    scene = dev.upload(world)
+    dev.set_pool(64.0)
+    dev.set_counting(True)
+    st = Stats()
+    try:
+        got = scene.color_at(rays, 5, st)
+    finally:
+        dev.set_counting(False)
+        dev.set_pool(8.0)
+        scene.close()
+    want = oracle.color_at(world, rays, 5, real_bits, threads=THREADS)
+    tol = 1e-4 if real_bits == 64 else 2e-2
+    bad = (np.abs(got - want).max(axis=1) > tol).mean()
+    from raytracer_amd import _abi
+    searched = sum(int(st.launch_box_tests[i]) for i in range(st.n_launch) if st.launch_kind[i] == _abi.K_SPAWN)
+    print(f"glass ball {where}, real={real_bits}: {bad:.3%} of {n} rays differ by more than {tol}; box tests of the n1/n2 search: {searched}")
+    assert bad <= (0.004 if real_bits == 64 else 0.03)
+    assert (searched == 0) == (where == "between-the-teapots")
+
+
 @pytest.mark.parametrize("real_bits", [64, 32])
 def test_group_transformed_meshes_as_instances(oracle, real_bits):
     """16 copies of teapot-low.obj under 16 groups with transformations of their own, flattened the reference's way
