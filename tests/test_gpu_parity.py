@@ -648,6 +648,21 @@ def test_refractive_indices_of_a_glass_shape_alone_in_its_box(dev, oracle, case,
     assert (searched == 0) == (case == "apart")
 
 
+def test_reciprocal_square_root_is_good_to_an_ulp():
+    """normalize() and the shadow ray multiply by 1 / |v| from the hardware's reciprocal square root and two Newton
+    steps (kernels.h, inv_sqrt<double>) where nalgebra divides by a square root: tests/cpp/inv_sqrt_check.hip runs the
+    kernels' own function over a million arguments across 160 binades against the long-double value and fails beyond
+    1.5 units of the last place (the square root and the division it replaces are good to one between them)."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "inv_sqrt_check")
+    assert os.path.exists(exe), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(r.stdout.strip())
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert float(r.stdout.split("largest error")[1].split()[0]) <= 1.5
+
+
 def test_cpp_host_mirror_renders_like_the_python_one(tmp_path):
     """include/rt355.hpp: the reference's camera test (src/camera.rs:155-169) and its default scene
     (src/main.rs:202-273) written against the C++ mirror; the canvas must equal the one the Python mirror
