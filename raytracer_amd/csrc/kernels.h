@@ -432,6 +432,12 @@ RT_FN bool slab_test(const SlabRay& s, float lox, float loy, float loz, float hi
 template <class R, int MODE, class Vis>
 RT_FN bool walk(const DevScene<R>& sc, int root, V3<R> o, V3<R> d, Vis& vis, Work& wk, int* lds, int* spill, const int sp0) {
   const SlabRay sr = make_slab_ray(o, d, sc.box_abs_max);
+  // every visitor's lower bound is fixed for the length of a traversal; the upper one moves with the hits
+  float tlo;
+  {
+    const float a = (float)vis.tmin();
+    tlo = a - fabsf(a) * 1.1920929e-7f;
+  }
   int sp = sp0;
   int cur = root;
   for (;;) {
@@ -446,8 +452,11 @@ RT_FN bool walk(const DevScene<R>& sc, int root, V3<R> o, V3<R> d, Vis& vis, Wor
 #endif
     if (cur >= 0) {
       const BvhNode4 N = sc.nodes[cur];
-      float tlo, thi;
-      slab_interval(vis.tmin(), vis.tmax(), tlo, thi);
+      float thi;
+      {
+        const float b = (float)vis.tmax();
+        thi = fminf(b + fabsf(b) * 1.1920929e-7f, 3.4028235e38f);  // finite: an empty child slot (x planes at +inf) then never passes
+      }
       // entry parameter of every child the ray may touch, +inf for the others
       float k0, k1, k2, k3;
       if (!slab_test(sr, N.box[0][0], N.box[0][2], N.box[0][4], N.box[0][1], N.box[0][3], N.box[0][5], tlo, thi, k0)) k0 = INFINITY;

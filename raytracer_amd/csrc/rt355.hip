@@ -56,8 +56,9 @@ int scratch_address(int device, void** out) {
 
 namespace {
 
-// hsize / vsize as the integers the reference keeps them in (usize, src/camera.rs:12-13).  Checked before
-// any cast or allocation: NaN, infinities, sizes below 1 or beyond what a canvas can be are rejected.
+// hsize / vsize as the integers the reference loops over: it keeps them as f32 (src/camera.rs:12-13) and renders
+// `0..(size as usize)` rows and columns (src/camera.rs:76-77, :84-85).  Checked before any cast or allocation: NaN,
+// infinities, sizes below 1 or beyond what a canvas can be are rejected.
 constexpr float MAX_CANVAS_EDGE = 65536.f;
 int camera_dims(const rt355_camera_desc* c, int& w, int& h) {
   if (!c) return set_err(RT355_EINVAL, "null camera");
