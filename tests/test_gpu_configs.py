@@ -465,6 +465,56 @@ def test_the_teapot_as_the_references_own_parser_builds_it(oracle, real_bits, me
     assert frac <= (0.004 if real_bits == 64 else 0.02)
 
 
+@pytest.mark.parametrize("real_bits", [64, 32])
+def test_headline_frame_is_linear_in_the_light(real_bits):
+    """A property that holds at any size and needs no oracle: every term of Material::lighting
+    (src/material.rs:108-162) carries the light's intensity once, per channel, and shade_hit (src/world.rs:104-127)
+    only adds and scales colours, so the frame is linear in the intensity.  Scaled by powers of two -- every product
+    and sum then scales exactly -- the headline frame at its full 1920x1080 must come out scaled bit for bit, through
+    all six generations, the Schlick mix and the conversion to the float canvas."""
+    world, cam = scenes.north_star(1920, 1080)
+    dev = Device.get(0, real_bits)
+    scene = dev.upload(world)
+    try:
+        base = scene.render(cam, 5).pixels.copy()
+    finally:
+        scene.close()
+    factor = np.asarray([0.5, 0.25, 2.0], dtype=np.float32)
+    li = world.pointlight.intensity
+    world.pointlight.intensity = tuple(float(a) * float(f) for a, f in zip(li, factor))
+    scene = dev.upload(world)
+    try:
+        scaled = scene.render(cam, 5).pixels.copy()
+    finally:
+        scene.close()
+    assert base.max() > 0.5 and np.isfinite(base).all()
+    assert np.array_equal(scaled, base * factor)
+
+
+def test_generations_do_not_depend_on_the_depth_limit():
+    """Another size-independent property, at the headline's full size: a ray of generation g exists and hits
+    whatever `remaining` it started from, as long as g is within the limit (src/world.rs:69, :79 only ask whether
+    remaining is zero).  Rendered with depth limits 2, 3 and 5, the frame must trace the same number of rays and
+    count the same hits in every generation the limits share, and a limit of 0 is the primary rays alone."""
+    world, cam = scenes.north_star(1920, 1080)
+    dev = Device.get(0, 64)
+    scene = dev.upload(world)
+    stats = {}
+    try:
+        for depth in (0, 2, 3, 5):
+            st = Stats()
+            scene.render(cam, depth, st)
+            stats[depth] = ([int(x) for x in st.radiance_rays], [int(x) for x in st.hits])
+    finally:
+        scene.close()
+    full_rays, full_hits = stats[5]
+    for depth in (0, 2, 3):
+        rays, hits = stats[depth]
+        assert rays[: depth + 1] == full_rays[: depth + 1] and hits[: depth + 1] == full_hits[: depth + 1], (depth, rays, full_rays)
+        assert not any(rays[depth + 1:]) and not any(hits[depth + 1:])
+    assert full_rays[0] >= 1920 * 1080 and all(full_rays[g + 1] <= 2 * full_hits[g] for g in range(5))
+
+
 def test_negative_coefficients_follow_the_reference(oracle):
     """src/world.rs:69,79 test `== 0.0` (a negative reflective / transparency still spawns its ray, weighted
     negatively) while src/world.rs:120 tests `> 0.0` (Schlick only when both are positive)."""
